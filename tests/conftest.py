@@ -1,0 +1,67 @@
+"""pytest plumbing: markers, import paths, golden-fixture access.
+
+`-m "not gpu"`: oracle vs golden vectors, host logic, C-ABI export check, gloo world_size-2 DP tests.
+`-m gpu`      : the parity tests proper -- HIP path (through the C-ABI) vs oracle / golden vectors.
+The oracle (oracle/) is put on sys.path HERE only: it is test infrastructure, never product code.
+"""
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG = os.path.join(ROOT, "nn-with-pytorch-personalized-losses_amd")
+for p in (PKG, os.path.join(ROOT, "oracle"), ROOT):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+class Golden:
+    """One fixture group: manifest cases + lazily loaded arrays (numpy.load, allow_pickle=False)."""
+
+    def __init__(self, group):
+        with open(os.path.join(GOLDEN, "manifest.json")) as f:
+            self.cases = json.load(f)[group]
+        self.npz = np.load(os.path.join(GOLDEN, f"{group}.npz"), allow_pickle=False)
+
+    def arr(self, case, name):
+        return self.npz[f"{case['id']}/{name}"]
+
+    def has(self, case, name):
+        return f"{case['id']}/{name}" in self.npz.files
+
+
+_cache = {}
+
+
+def golden(group):
+    if group not in _cache:
+        _cache[group] = Golden(group)
+    return _cache[group]
+
+
+def golden_cases(group):
+    with open(os.path.join(GOLDEN, "manifest.json")) as f:
+        return json.load(f)[group]
+
+
+def relerr(a, b):
+    """max|a-b| / max|b| -- the parity metric fixed in SURVEY 8(c) / BASELINE.md (1e-5 bar)."""
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    if a.size == 0:
+        return 0.0
+    return float(np.abs(a - b).max()) / max(float(np.abs(b).max()), 1e-30)
+
+
+@pytest.fixture(scope="session")
+def root():
+    return ROOT
