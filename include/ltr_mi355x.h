@@ -1,0 +1,108 @@
+/*
+ * ltr_mi355x.h -- C ABI of libltr_mi355x.so: the MI355X (gfx950) listwise learning-to-rank hot path.
+ *
+ * The reference (Haiga/nn-with-pytorch-personalized-losses) has no FFI layer: its boundary for this path
+ * is the Python import surface.  Every entry point below therefore replaces one
+ * reference *Python function* (file:line given per entry); the Python host code under
+ * nn-with-pytorch-personalized-losses_amd/{losses,architeture}/ keeps the reference's names/signatures and
+ * binds these symbols through ctypes (see INTEGRATION.md for the binding stub).
+ *
+ * Conventions
+ *   - All pointers are DEVICE pointers (HBM) unless marked host.  Row-major, contiguous, fp32 unless noted.
+ *   - `stream` is a hipStream_t passed as void*.  Launchers never allocate, never synchronise, never throw.
+ *   - Return value: 0 = launched; < 0 = argument rejected before any launch (LTR_ERR_*); > 0 = hipError_t.
+ *   - "slate" = one query's documents; B slates of S documents each; F features per document.
+ *   - Per-slate partial results are written; the final mean/sum over slates is a deterministic
+ *     fixed-order reduction (ltr_reduce_sum_f32), never a float atomic.
+ */
+#ifndef LTR_MI355X_H
+#define LTR_MI355X_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LTR_ABI_VERSION 1
+
+enum {
+    LTR_OK = 0,
+    LTR_ERR_NULL = -1,   /* required pointer is NULL                      */
+    LTR_ERR_SHAPE = -2,  /* B/S/F/n outside what the kernels support       */
+    LTR_ERR_PARAM = -3,  /* bad enum / scalar (scheme id, log base, ...)   */
+    LTR_ERR_ALIGN = -4   /* pointer not aligned as the entry point states  */
+};
+
+/* Largest slate length the loss kernels take (LDS-resident slate state). */
+#define LTR_MAX_SLATE 2048
+
+/* lambdaLoss weighing schemes, losses/lambdaL.py:96-127 (string-dispatched there, :46). */
+enum {
+    LTR_SCHEME_NONE = 0,                 /* weighing_scheme=None                      -> w = 1              */
+    LTR_SCHEME_NDCG_LOSS1 = 1,           /* ndcgLoss1_scheme                  :96-97                        */
+    LTR_SCHEME_NDCG_LOSS2 = 2,           /* ndcgLoss2_scheme                  :100-106                      */
+    LTR_SCHEME_LAMBDA_RANK = 3,          /* lamdbaRank_scheme [sic]           :109-111                      */
+    LTR_SCHEME_NDCG_LOSS2PP = 4,         /* ndcgLoss2PP_scheme                :114-115                      */
+    LTR_SCHEME_RANKNET = 5,              /* rankNet_scheme                    :118-119                      */
+    LTR_SCHEME_RANKNET_GT_DIFF = 6,      /* rankNetWeightedByGTDiff_scheme    :122-123                      */
+    LTR_SCHEME_RANKNET_GT_DIFF_POW = 7   /* rankNetWeightedByGTDiffPowed_scheme :126-127                    */
+};
+enum { LTR_LOG_BINARY = 0, LTR_LOG_NATURAL = 1 }; /* reduction_log, lambdaL.py:52-57 */
+
+int ltr_abi_version(void);
+/* Static description of a return code (LTR_ERR_* or hipError_t). Host pointer, never NULL. */
+const char *ltr_error_string(int code);
+
+/* out[0] = scale * sum(in[0..n)), fixed summation order (bit-reproducible). */
+int ltr_reduce_sum_f32(const float *in, int64_t n, float scale, float *out, void *stream);
+
+/* ---- approxNDCGLoss(y_pred, y_true, eps, padded_value_indicator, alpha)   losses/approxNDCG.py:7-53
+ * One pass, one workgroup-slice per slate: soft ranks from pairwise sigmoids in LDS, forward and
+ * analytic backward together.
+ *   slate_loss[b] = -sum_i G_i / log2(1 + pos_i)            (caller averages: loss = mean_b, :53)
+ *   dscores[b,i]  = grad_scale * d slate_loss[b] / d scores[b,i]   (NULL: forward only)
+ * labels == pad marks padding (:22-24).  grad_scale is normally 1/B_global. */
+int ltr_approxndcg_fwd_bwd(const float *scores, const float *labels, int B, int S, float alpha, float eps,
+                           float pad, float grad_scale, float *slate_loss, float *dscores, void *stream);
+
+/* ---- listnetLoss(y_true, y_predicted, apply_sigmoid)                        losses/listnet.py:5-16
+ *   slate_loss[b] = -sum_i p_i log q_i   (p = softmax(y_true), q = softmax(y_pred); caller SUMS, :16)
+ *   dscores[b,i]  = grad_scale * (q_i sum(p) - p_i);  apply_sigmoid != 0: the :13-15 variant. */
+int ltr_listnet_fwd_bwd(const float *y_true, const float *y_pred, int B, int S, int apply_sigmoid,
+                        float grad_scale, float *slate_loss, float *dscores, void *stream);
+
+/* ---- lambdaLoss(...)                                                   losses/lambdaL.py:67-93 (+7-64)
+ *   slate_loss[b]  = -sum over kept pairs of log_b(clamp(clamp(sigmoid(sigma d), eps)^w, eps))
+ *   slate_count[b] = number of kept pairs (for reduction="mean": loss = sum(slate_loss)/sum(count))
+ *   dscores[b,i]   = grad_scale * d slate_loss[b] / d scores[b,i]  (NULL: forward only)
+ * k <= 0 means k=None (no truncation).  Ranks by counting, ties by index. */
+int ltr_lambda_fwd_bwd(const float *scores, const float *labels, int B, int S, int scheme, int k, float sigma,
+                       float mu, float eps, float pad, int log_base, float grad_scale, float *slate_loss,
+                       float *slate_count, float *dscores, void *stream);
+
+/* ---- lambdaMask(..., return_losses=True)                                losses/lambdaL.py:7-60
+ * losses[b, ri, rj] for ALL pairs in predicted-rank order (ri, rj = 0-based ranks), optional keep mask
+ * (the boolean mask of :62, 1 byte per pair) and rank[b, i] = predicted rank of document i. */
+int ltr_lambda_pairs_fwd(const float *scores, const float *labels, int B, int S, int scheme, int k, float sigma,
+                         float mu, float eps, float pad, int log_base, float *losses, uint8_t *keep,
+                         int32_t *rank, void *stream);
+/* Backward of the above: dscores[b,i] = sum_{pairs} grad_losses[b,ri,rj] * d losses[b,ri,rj] / d scores[b,i]. */
+int ltr_lambda_pairs_bwd(const float *scores, const float *labels, int B, int S, int scheme, int k, float sigma,
+                         float mu, float eps, float pad, int log_base, const float *grad_losses,
+                         float *dscores, void *stream);
+
+/* ---- ordinalLoss(y_pred[B,S,n], y_true[B,S], n, padded_value_indicator)  losses/ordinal.py:27-53
+ * n_docs = B*S documents, n ordinal probabilities each.  Targets 1[y >= k] are built with the default
+ * indicator -1 (ordinal.py:39), then entries whose target == pad are masked (:41-45).
+ *   sums[0] = sum of masked BCE terms, sums[1] = number of documents with >= 1 unmasked target
+ *   dpred[doc,k] = (p - t) / max((1-p) p, 1e-12), 0 where masked  (caller scales by 1/sums[1])
+ * block_partials: workspace of 2*ltr_ordinal_num_blocks(n_docs) floats. */
+int64_t ltr_ordinal_num_blocks(int64_t n_docs);
+int ltr_ordinal_fwd_bwd(const float *y_pred, const float *y_true, int64_t n_docs, int n, float pad,
+                        float *block_partials, float *sums, float *dpred, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LTR_MI355X_H */

@@ -1,0 +1,121 @@
+// ltr_device.h -- device-side building blocks shared by the gfx950 listwise-LTR kernels.
+//
+// A *slate group* is the set of threads (64..1024, power of two) that cooperates on one slate whose
+// state (scores, labels, gains, ...) is staged in LDS.  Rows i of the S x S pair matrix are spread over
+// `sp` row lanes, and when the group has more threads than rows the columns j are split over
+// CG = group / sp column groups; partial row sums are combined in a FIXED order through LDS so every
+// result is bit-reproducible (no float atomics anywhere in this library).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define LTR_WAVE 64
+#define LTR_LN2 0.69314718055994530942f
+
+namespace ltr {
+
+struct SlateGroup {
+    int S;      // documents in the slate
+    int group;  // threads cooperating on the slate
+    int sp;     // row lanes  = min(nextpow2(S), group)
+    int CG;     // column groups = group / sp
+    int t;      // thread index inside the group
+    int ri;     // row lane   = t % sp
+    int cg;     // column grp = t / sp
+    int wig;    // wave index inside the group
+    int nw;     // waves per group
+    float *part;  // LDS [group]  row-partial scratch
+    float *red;   // LDS [32]     cross-wave scratch
+};
+
+__device__ __forceinline__ float wave_allsum(float v) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, LTR_WAVE);
+    return v;  // butterfly: every lane holds the same bits
+}
+
+__device__ __forceinline__ float wave_allmax(float v) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, LTR_WAVE));
+    return v;
+}
+
+// Sum over all threads of the slate group; every thread gets the total.  All threads of the BLOCK must
+// call it (uniform __syncthreads count).
+__device__ __forceinline__ float group_sum(const SlateGroup &g, float v) {
+    v = wave_allsum(v);
+    if (g.nw == 1) return v;
+    __syncthreads();
+    if ((threadIdx.x & (LTR_WAVE - 1)) == 0) g.red[g.wig] = v;
+    __syncthreads();
+    float s = 0.f;
+    for (int w = 0; w < g.nw; ++w) s += g.red[w];
+    return s;
+}
+
+__device__ __forceinline__ float group_max(const SlateGroup &g, float v) {
+    v = wave_allmax(v);
+    if (g.nw == 1) return v;
+    __syncthreads();
+    if ((threadIdx.x & (LTR_WAVE - 1)) == 0) g.red[g.wig] = v;
+    __syncthreads();
+    float s = g.red[0];
+    for (int w = 1; w < g.nw; ++w) s = fmaxf(s, g.red[w]);
+    return s;
+}
+
+// Combine the CG column-group partials of each row: returns sum_c v(row, c) to every replica of the row.
+__device__ __forceinline__ float row_reduce(const SlateGroup &g, float v) {
+    if (g.CG == 1) return v;
+    __syncthreads();
+    g.part[g.t] = v;
+    __syncthreads();
+    float s = 0.f;
+    for (int c = 0; c < g.CG; ++c) s += g.part[c * g.sp + g.ri];
+    return s;
+}
+
+__host__ __device__ inline int next_pow2(int v) {
+    int p = 1;
+    while (p < v) p <<= 1;
+    return p;
+}
+
+// Threads per slate: two threads per row when possible (halves the serial j sweep), one wave minimum.
+inline int pick_group(int S) {
+    int g = next_pow2(2 * S);
+    if (g < 64) g = 64;
+    if (g > 1024) g = 1024;
+    return g;
+}
+
+__device__ __forceinline__ SlateGroup make_group(int S, int group, float *scratch /* [group + 32] */) {
+    SlateGroup g;
+    g.S = S;
+    g.group = group;
+    int np2 = next_pow2(S);
+    g.sp = np2 < group ? np2 : group;
+    g.CG = group / g.sp;
+    int gid = threadIdx.x / group;
+    g.t = threadIdx.x - gid * group;
+    g.ri = g.t & (g.sp - 1);
+    g.cg = g.t / g.sp;
+    g.wig = g.t / LTR_WAVE;
+    g.nw = group / LTR_WAVE;
+    g.part = scratch;
+    g.red = scratch + group;
+    return g;
+}
+
+// sigmoid pair of x: big = sigma(|x|), small = sigma(-|x|), without overflow and with full relative
+// precision on the small side (small = e * big, e = exp(-|x|)).
+__device__ __forceinline__ void sigmoid_pair(float x, float &s_pos, float &s_neg) {
+    float e = __expf(-fabsf(x));
+    float r = __frcp_rn(1.f + e);
+    float big = r, small = e * r;
+    bool nonneg = x >= 0.f;
+    s_pos = nonneg ? big : small;   // sigmoid(x)
+    s_neg = nonneg ? small : big;   // sigmoid(-x)
+}
+
+}  // namespace ltr

@@ -1,0 +1,648 @@
+// ltr_scorer.hip -- the slate pipeline: FC scorer forward -> listwise loss -> scorer backward -> weight
+// gradients, one persistent workgroup per CU, X read from HBM exactly once (gfx950 / MI355X).
+//
+// Replaces, behind the reference's nn.Module surface:
+//   architeture/doubleLayer.py:54-73  DoubleLayerNet  fc3(drop(relu(fc2(drop(relu(fc1 x))))))
+//   architeture/tripleLayer.py:5-17   TripleLayerNet  l3(sigmoid(l2(l1 x)))
+// and, in fused mode, the scorer->loss->backward chain of main_batch_execution.py:128-170.
+//
+// Layout of the computation (see DESIGN.md "slate pipeline"):
+//   * workgroup = 4 waves (one per SIMD, up to 512 VGPRs each); a SUPER-TILE is 128 consecutive documents
+//     (= 1 slate of 128, 2 of 64, 4 of 32); wave w owns documents 32w..32w+31 as two 16-document tiles.
+//   * every FC layer is computed TRANSPOSED with v_mfma_f32_16x16x4_f32 (exact fp32):
+//         z^T[n][doc] = sum_f W[n][f] x^T[f][doc]      A = W fragment, B = activations, lane&15 = document.
+//     The accumulator layout (row = 4*(lane>>4)+reg = output feature, col = lane&15 = document) is exactly
+//     the B-operand layout of the next layer when k-step s of input tile T covers features 16T+4q+s, so
+//     activations NEVER leave the wave's registers between layers.  Biases ride along as a ones feature.
+//   * weight fragments are pre-packed in lane order (one coalesced 1 KiB load per 16x16 tile of W, L2-hot).
+//   * only the weight gradients dW = dz^T h contract over DOCUMENTS: dz and h tiles of a 64-document chunk
+//     are staged in LDS ([doc][feature], stride 144 -> conflict-free fragment reads) and each wave owns a
+//     quarter of the dW tiles, accumulated in registers across the whole persistent loop; X is staged in
+//     LDS once per super-tile and serves both fc1 (B operand) and dW1 (B operand).
+//   * per-workgroup dW partials go to a workspace and are summed in a FIXED order by a second kernel
+//     (no float atomics: bit-reproducible gradients).
+#include "../../include/ltr_mi355x.h"
+#include "ltr_slate_losses.h"
+
+using namespace ltr;
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+constexpr int kTileDocs = 128;   // documents per super-tile
+constexpr int kWaves = 4;
+constexpr int kThreads = 256;
+constexpr int kChunkDocs = 64;   // documents per dW staging chunk (one 16-doc tile of every wave)
+
+enum { ACT_ID = 0, ACT_RELU_DROP = 1, ACT_SIGMOID = 2 };
+enum { MODE_FWD = 0, MODE_BWD = 1, MODE_FUSED = 2 };
+
+template <int F_, int H1_, int H2_, int A1_, int A2_>
+struct NetT {
+    static constexpr int F = F_, H1 = H1_, H2 = H2_, A1 = A1_, A2 = A2_;
+    static constexpr int XT = (F + 1 + 15) / 16;    // x tiles incl. the ones feature at index F
+    static constexpr int NT1 = (H1 + 15) / 16;      // fc1 output tiles
+    static constexpr int H1T = (H1 + 1 + 15) / 16;  // h1 tiles incl. the ones feature at index H1
+    static constexpr int NT2 = (H2 + 15) / 16;      // fc2 output tiles
+    static constexpr int LD = (XT > H1T ? XT : H1T) * 16;   // LDS row stride in floats (144: LD % 32 == 16)
+    static constexpr int NW1 = NT1 * XT;            // dW1 tiles  [H1 rows][F+1 cols]
+    static constexpr int NW2 = NT2 * H1T;           // dW2 tiles  [H2 rows][H1+1 cols]
+    static constexpr int TW1 = (NW1 + kWaves - 1) / kWaves;
+    static constexpr int TW2 = (NW2 + kWaves - 1) / kWaves;
+    // packed weights (floats)
+    static constexpr int W1F_OFF = 0;                          // [NT1][XT][64][4]
+    static constexpr int W2F_OFF = W1F_OFF + NT1 * XT * 256;   // [NT2][H1T][64][4]
+    static constexpr int W2T_OFF = W2F_OFF + NT2 * H1T * 256;  // [NT1][NT2][64][4]
+    static constexpr int W3_OFF = W2T_OFF + NT1 * NT2 * 256;   // [NT2*16] then b3
+    static constexpr int PACKED = W3_OFF + NT2 * 16 + 16;
+    // per-workgroup gradient partial (floats)
+    static constexpr int P_W1 = 0;                             // [NT1*16][XT*16]
+    static constexpr int P_W2 = P_W1 + NT1 * 16 * XT * 16;     // [NT2*16][H1T*16]
+    static constexpr int P_W3 = P_W2 + NT2 * 16 * H1T * 16;    // [NT2*16]
+    static constexpr int P_B3 = P_W3 + NT2 * 16;
+    static constexpr int PART = P_B3 + 16;
+    static constexpr int NPARAM = H1 * F + H1 + H2 * H1 + H2 + H2 + 1;
+    static_assert(LD % 32 == 16, "LDS stride must be 16 mod 32 for conflict-free fragment reads");
+    static_assert(F % 4 == 0 && H1 % 4 == 0 && H2 % 4 == 0, "feature counts must be multiples of 4");
+};
+using DoubleNet = NetT<136, 136, 136, ACT_RELU_DROP, ACT_RELU_DROP>;   // doubleLayer.py:54-66
+using TripleNet = NetT<136, 64, 32, ACT_ID, ACT_SIGMOID>;              // tripleLayer.py:5-17
+
+struct PipeArgs {
+    const float *X;          // [n_docs][F]
+    long long n_docs;
+    const float *labels;     // fused: [B*S]
+    int B, S;
+    const float *packed;     // NetT::PACKED floats
+    float *scores_out;       // MODE_FWD : [n_docs]
+    const float *dscores_in; // MODE_BWD : [n_docs]
+    float *slate_loss;       // MODE_FUSED: [B]
+    float *partials;         // [grid][PART]
+    const uint8_t *keep1;    // optional explicit dropout keep masks [n_docs][H1] / [n_docs][H2]
+    const uint8_t *keep2;
+    unsigned long long seed;
+    int dropout;             // 1: training-mode dropout p = 0.5 on ACT_RELU_DROP layers
+    int loss_kind;           // 0 approxNDCG, 1 ListNet
+    float alpha, eps, pad, gscale;
+    int apply_sigmoid;
+    int n_super;
+};
+
+__device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+__device__ __forceinline__ unsigned mix32(unsigned h) {
+    h ^= h >> 16; h *= 0x85EBCA6Bu; h ^= h >> 13; h *= 0xC2B2AE35u; h ^= h >> 16;
+    return h;
+}
+
+// 32 keep bits for features [32*word, 32*word+32) of document `doc` in dropout layer `layer`.
+__device__ __forceinline__ unsigned keep_word(unsigned long long seed, int layer, long long doc, int word) {
+    unsigned h = (unsigned)seed ^ (0x9E3779B9u * (unsigned)(layer + 1));
+    h = mix32(h ^ (unsigned)doc);
+    h = mix32(h ^ (unsigned)((unsigned long long)doc >> 32) ^ (unsigned)(seed >> 32));
+    return mix32(h + 0x27D4EB2Fu * (unsigned)(word + 1));
+}
+
+// z^T tiles = W fragments x B fragments for BOTH 16-document tiles of the wave.
+// wf: [NT][KT][64] float4, lane-ordered; lane (q = lane>>4, i = lane&15) holds W[16*To + i][16*T + 4q + s], s = 0..3.
+template <int NT, int KT, int KMAX, int NMAX>
+__device__ __forceinline__ void gemm_wx(const f32x4 *__restrict__ wf, int lane, const f32x4 (&bin)[2][KMAX],
+                                        f32x4 (&out)[2][NMAX]) {
+#pragma unroll
+    for (int To = 0; To < NT; ++To) {
+        f32x4 c0 = {0.f, 0.f, 0.f, 0.f}, c1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int T = 0; T < KT; ++T) {
+            const f32x4 a = wf[(To * KT + T) * 64 + lane];
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                c0 = mfma4(a[s], bin[0][T][s], c0);
+                c1 = mfma4(a[s], bin[1][T][s], c1);
+            }
+        }
+        out[0][To] = c0;
+        out[1][To] = c1;
+    }
+}
+
+// Activation (+ dropout) on accumulator tiles; features >= H forced to 0, then the ones feature at index H.
+template <int ACT, int H, int NT, int NMAX>
+__device__ __forceinline__ void activate(f32x4 (&h)[2][NMAX], int q, const PipeArgs &a, int layer,
+                                         const uint8_t *keep, long long doc0, long long doc1) {
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const long long doc = t == 0 ? doc0 : doc1;
+        const bool in_range = doc < a.n_docs;
+#pragma unroll
+        for (int To = 0; To < NT; ++To) {
+            unsigned kb = 0xFu;
+            if (ACT == ACT_RELU_DROP && a.dropout) {
+                if (keep) {
+                    const int n0 = 16 * To + 4 * q;
+                    unsigned bytes = 0;
+                    if (in_range && n0 < H) bytes = *reinterpret_cast<const unsigned *>(keep + doc * H + n0);
+                    kb = ((bytes & 0xFFu) ? 1u : 0u) | ((bytes & 0xFF00u) ? 2u : 0u) | ((bytes & 0xFF0000u) ? 4u : 0u) |
+                         ((bytes & 0xFF000000u) ? 8u : 0u);
+                } else {
+                    const unsigned wbits = keep_word(a.seed, layer, doc, To >> 1);
+                    kb = (wbits >> (16 * (To & 1) + 4 * q)) & 0xFu;
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int n = 16 * To + 4 * q + r;
+                float v = h[t][To][r];
+                if (ACT == ACT_RELU_DROP) {
+                    v = fmaxf(v, 0.f);
+                    if (a.dropout) v = ((kb >> r) & 1u) ? 2.f * v : 0.f;
+                } else if (ACT == ACT_SIGMOID) {
+                    v = 1.f / (1.f + __expf(-v));
+                }
+                h[t][To][r] = (n < H) ? v : 0.f;
+            }
+        }
+    }
+}
+
+template <int ACT>
+__device__ __forceinline__ float act_grad(float h, int dropout) {
+    if (ACT == ACT_RELU_DROP) return h > 0.f ? (dropout ? 2.f : 1.f) : 0.f;
+    if (ACT == ACT_SIGMOID) return h * (1.f - h);
+    return 1.f;
+}
+
+// dW tiles of this wave += A^T B over one 64-document chunk.
+//   As: LDS [64][LD]   rows = chunk documents, A fragment = As[4s+q][16*To + (lane&15)]
+//   Bs: LDS base of the B rows; row of chunk document c is Bs[brow(c)*LD ...]
+template <int TW, int NTI, int NTOT, int LD, class BRow>
+__device__ __forceinline__ void dw_chunk(f32x4 (&acc)[TW], const float *As, const float *Bs, int w, int lane, BRow brow) {
+    const int q = lane >> 4, i = lane & 15;
+#pragma unroll 2
+    for (int s = 0; s < kChunkDocs / 4; ++s) {
+        const float *arow = As + (4 * s + q) * LD + i;
+        const float *brw = Bs + brow(4 * s + q) * LD + i;
+#pragma unroll
+        for (int n = 0; n < TW; ++n) {
+            const int idx = w + kWaves * n;
+            if (idx < NTOT) {   // wave-uniform
+                const int To = idx / NTI, Ti = idx - To * NTI;
+                acc[n] = mfma4(arow[16 * To], brw[16 * Ti], acc[n]);
+            }
+        }
+    }
+}
+
+template <class N, int MODE>
+__global__ void __launch_bounds__(kThreads, 1) slate_pipeline_kernel(const PipeArgs a) {
+    constexpr int LD = N::LD;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float *Xs = smem;                         // [128][LD]
+    float *Ds = Xs + kTileDocs * LD;          // [64][LD]   dz chunk (A operand of dW)
+    float *Hs = Ds + kChunkDocs * LD;         // [64][LD]   h1 chunk (B operand of dW2)
+    float *sc = Hs + kChunkDocs * LD;         // [128] scores
+    float *yl = sc + kTileDocs;               // [128] labels (-inf padded)
+    float *gn = yl + kTileDocs;               // [128] gains
+    float *gg = gn + kTileDocs;               // [128] loss scratch
+    float *dsc = gg + kTileDocs;              // [128] d loss / d score
+    float *w3s = dsc + kTileDocs;             // [NT2*16 + 16] w3 (zero padded), b3
+    float *dw3 = w3s + N::NT2 * 16 + 16;      // [4][NT2*16] per-wave dw3 accumulators
+    float *scratch = dw3 + kWaves * N::NT2 * 16;   // [256 + 128] slate-group scratch
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int q = lane >> 4, d = lane & 15;
+
+    const f32x4 *W1F = reinterpret_cast<const f32x4 *>(a.packed + N::W1F_OFF);
+    const f32x4 *W2F = reinterpret_cast<const f32x4 *>(a.packed + N::W2F_OFF);
+    const f32x4 *W2T = reinterpret_cast<const f32x4 *>(a.packed + N::W2T_OFF);
+
+    for (int j = tid; j < N::NT2 * 16 + 16; j += kThreads) w3s[j] = a.packed[N::W3_OFF + j];
+    for (int j = tid; j < kWaves * N::NT2 * 16; j += kThreads) dw3[j] = 0.f;
+    float db3 = 0.f;
+    f32x4 accW1[N::TW1], accW2[N::TW2];
+    if (MODE != MODE_FWD) {
+#pragma unroll
+        for (int n = 0; n < N::TW1; ++n) accW1[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int n = 0; n < N::TW2; ++n) accW2[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+
+    for (int st = blockIdx.x; st < a.n_super; st += gridDim.x) {
+        const long long doc_base = (long long)st * kTileDocs;
+        __syncthreads();   // previous super-tile done with Xs / sc / dsc
+        // ---- X: HBM -> LDS, coalesced 16 B per lane; the wave's 32 documents are contiguous in memory.
+        {
+            constexpr int V4_PER_ROW = N::F / 4;
+            constexpr int V4 = 32 * V4_PER_ROW;             // float4s per wave
+            const long long row0 = doc_base + 32 * w;
+            const f32x4 *src = reinterpret_cast<const f32x4 *>(a.X + row0 * N::F);
+#pragma unroll
+            for (int m = 0; m < (V4 + 63) / 64; ++m) {
+                const int e = lane + 64 * m;
+                if (e < V4) {
+                    const int r = e / V4_PER_ROW, c4 = e - r * V4_PER_ROW;
+                    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                    if (row0 + r < a.n_docs) v = src[e];
+                    *reinterpret_cast<f32x4 *>(Xs + (32 * w + r) * LD + 4 * c4) = v;
+                }
+            }
+            // ones feature at column F, zeros up to LD
+            for (int e = lane; e < 32 * ((LD - N::F) / 4); e += 64) {
+                const int r = e / ((LD - N::F) / 4), c4 = e - r * ((LD - N::F) / 4);
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if (c4 == 0) v[0] = 1.f;
+                *reinterpret_cast<f32x4 *>(Xs + (32 * w + r) * LD + N::F + 4 * c4) = v;
+            }
+        }
+        if (MODE == MODE_FUSED && tid < kTileDocs) {
+            const long long doc = doc_base + tid;
+            const float y = doc < (long long)a.B * a.S ? a.labels[doc] : a.pad;
+            if (a.loss_kind == 0) stage_label(y, a.pad, yl[tid], gn[tid]);
+            else yl[tid] = doc < (long long)a.B * a.S ? y : 0.f;
+        }
+        if (MODE == MODE_BWD && tid < kTileDocs) {
+            const long long doc = doc_base + tid;
+            dsc[tid] = doc < a.n_docs ? a.dscores_in[doc] : 0.f;
+        }
+        __syncthreads();
+
+        const long long gdoc0 = doc_base + 32 * w + d, gdoc1 = gdoc0 + 16;
+        // ---- fc1
+        f32x4 h1[2][N::H1T];
+        {
+            f32x4 xb[2][N::XT];
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int T = 0; T < N::XT; ++T)
+                    xb[t][T] = *reinterpret_cast<const f32x4 *>(Xs + (32 * w + 16 * t + d) * LD + 16 * T + 4 * q);
+            gemm_wx<N::NT1, N::XT>(W1F, lane, xb, h1);
+        }
+        if (N::H1T > N::NT1) {
+#pragma unroll
+            for (int t = 0; t < 2; ++t) h1[t][N::H1T - 1] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        activate<N::A1, N::H1, N::NT1>(h1, q, a, 0, a.keep1, gdoc0, gdoc1);
+        {   // ones feature at index H1 (carries b2 through fc2 and db2 through dW2)
+            constexpr int Tn = N::H1 / 16, p = N::H1 % 16;
+#pragma unroll
+            for (int t = 0; t < 2; ++t) h1[t][Tn][p % 4] = (q == p / 4) ? 1.f : h1[t][Tn][p % 4];
+        }
+        // ---- fc2
+        f32x4 h2[2][N::NT2];
+        gemm_wx<N::NT2, N::H1T>(W2F, lane, h1, h2);
+        activate<N::A2, N::H2, N::NT2>(h2, q, a, 1, a.keep2, gdoc0, gdoc1);
+        // ---- fc3: s = w3 . h2 + b3, reduced over the 4 q-lanes of each document
+        {
+            float p0 = 0.f, p1 = 0.f;
+#pragma unroll
+            for (int To = 0; To < N::NT2; ++To) {
+                const f32x4 wv = *reinterpret_cast<const f32x4 *>(w3s + 16 * To + 4 * q);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    p0 += wv[r] * h2[0][To][r];
+                    p1 += wv[r] * h2[1][To][r];
+                }
+            }
+            p0 += __shfl_xor(p0, 16, 64); p0 += __shfl_xor(p0, 32, 64);
+            p1 += __shfl_xor(p1, 16, 64); p1 += __shfl_xor(p1, 32, 64);
+            const float b3 = w3s[N::NT2 * 16];
+            if (q == 0) {
+                sc[32 * w + d] = p0 + b3;
+                sc[32 * w + 16 + d] = p1 + b3;
+            }
+        }
+        if (MODE == MODE_FWD) {
+            __syncthreads();
+            if (tid < kTileDocs && doc_base + tid < a.n_docs) a.scores_out[doc_base + tid] = sc[tid];
+            continue;
+        }
+        // ---- listwise loss on the LDS-resident scores (fused) -> dsc
+        if (MODE == MODE_FUSED) {
+            __syncthreads();
+            const int group = 2 * a.S;                 // S in {32, 64, 128}: 2 threads per document row
+            const int gid = tid / group;
+            const SlateGroup g = make_group(a.S, group, scratch + gid * (group + 32));
+            const int so = gid * a.S;
+            const long long slate = (long long)st * (kTileDocs / a.S) + gid;
+            float loss;
+            if (a.loss_kind == 0)
+                loss = approx_ndcg_slate(g, sc + so, yl + so, gn + so, gg + so, a.alpha, a.eps, a.gscale, true,
+                                         [&](int i, float v) { dsc[so + i] = v; });
+            else
+                loss = listnet_slate(g, yl + so, sc + so, a.apply_sigmoid != 0, a.gscale, true,
+                                     [&](int i, float v) { dsc[so + i] = v; });
+            if (g.t == 0 && slate < a.B) a.slate_loss[slate] = loss;
+        }
+        __syncthreads();
+
+        // ---- backward through fc3: dw3 += ds * h2 (sum over documents = lanes d), dz2 = ds * w3 * act2'(h2)
+        const float ds0 = dsc[32 * w + d], ds1 = dsc[32 * w + 16 + d];
+        {
+            float sb = (q == 0) ? ds0 + ds1 : 0.f;
+            db3 += wave_allsum(sb);
+        }
+#pragma unroll
+        for (int To = 0; To < N::NT2; ++To) {
+            const f32x4 wv = *reinterpret_cast<const f32x4 *>(w3s + 16 * To + 4 * q);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float v = ds0 * h2[0][To][r] + ds1 * h2[1][To][r];
+                v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64);
+                v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64);
+                if (d == 0) dw3[w * N::NT2 * 16 + 16 * To + 4 * q + r] += v;
+                h2[0][To][r] = ds0 * wv[r] * act_grad<N::A2>(h2[0][To][r], a.dropout);
+                h2[1][To][r] = ds1 * wv[r] * act_grad<N::A2>(h2[1][To][r], a.dropout);
+            }
+        }
+        // h2 now holds dz2.
+        // ---- dh1^T = W2^T dz2^T  (A = packed W2^T fragments, B = dz2 registers)
+        f32x4 dz1[2][N::NT1];
+        gemm_wx<N::NT1, N::NT2>(W2T, lane, h2, dz1);
+
+        // ---- dW2 += dz2^T [h1 | 1] over the two 64-document chunks
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            if (t > 0) __syncthreads();   // chunk 0 fully consumed
+#pragma unroll
+            for (int To = 0; To < N::NT2; ++To)
+                *reinterpret_cast<f32x4 *>(Ds + (16 * w + d) * LD + 16 * To + 4 * q) = h2[t][To];
+#pragma unroll
+            for (int T = 0; T < N::H1T; ++T)
+                *reinterpret_cast<f32x4 *>(Hs + (16 * w + d) * LD + 16 * T + 4 * q) = h1[t][T];
+            __syncthreads();
+            dw_chunk<N::TW2, N::H1T, N::NW2, LD>(accW2, Ds, Hs, w, lane, [](int c) { return c; });
+        }
+        // ---- dz1 = dh1 * act1'(h1), features >= H1 (incl. the ones feature) zeroed
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int To = 0; To < N::NT1; ++To)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int n = 16 * To + 4 * q + r;
+                    dz1[t][To][r] = (n < N::H1) ? dz1[t][To][r] * act_grad<N::A1>(h1[t][To][r], a.dropout) : 0.f;
+                }
+        // ---- dW1 += dz1^T [x | 1]; B operand straight from the X tile in LDS
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            __syncthreads();              // previous chunk's readers are done with Ds
+#pragma unroll
+            for (int To = 0; To < N::NT1; ++To)
+                *reinterpret_cast<f32x4 *>(Ds + (16 * w + d) * LD + 16 * To + 4 * q) = dz1[t][To];
+            __syncthreads();
+            dw_chunk<N::TW1, N::XT, N::NW1, LD>(accW1, Ds, Xs, w, lane,
+                                               [t](int c) { return 32 * (c >> 4) + 16 * t + (c & 15); });
+        }
+    }
+
+    if (MODE == MODE_FWD) return;
+    // ---- per-workgroup partial gradients -> workspace (accumulator layout: row = 4q + r, col = lane & 15)
+    float *part = a.partials + (size_t)blockIdx.x * N::PART;
+#pragma unroll
+    for (int n = 0; n < N::TW1; ++n) {
+        const int idx = w + kWaves * n;
+        if (idx < N::NW1) {
+            const int To = idx / N::XT, Ti = idx - To * N::XT;
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                part[N::P_W1 + (16 * To + 4 * q + r) * (N::XT * 16) + 16 * Ti + d] = accW1[n][r];
+        }
+    }
+#pragma unroll
+    for (int n = 0; n < N::TW2; ++n) {
+        const int idx = w + kWaves * n;
+        if (idx < N::NW2) {
+            const int To = idx / N::H1T, Ti = idx - To * N::H1T;
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                part[N::P_W2 + (16 * To + 4 * q + r) * (N::H1T * 16) + 16 * Ti + d] = accW2[n][r];
+        }
+    }
+    __syncthreads();
+    for (int j = tid; j < N::NT2 * 16; j += kThreads) {
+        float s = 0.f;
+        for (int ww = 0; ww < kWaves; ++ww) s += dw3[ww * N::NT2 * 16 + j];
+        part[N::P_W3 + j] = s;
+    }
+    // db3: every lane of a wave holds the wave's sum; combine the 4 waves through LDS in fixed order
+    if (lane == 0) scratch[w] = db3;
+    __syncthreads();
+    if (tid == 0) part[N::P_B3] = scratch[0] + scratch[1] + scratch[2] + scratch[3];
+}
+
+// Pack nn.Linear parameters into lane-ordered MFMA A-fragments (once per optimizer step; 37k params).
+template <class N>
+__global__ void pack_kernel(const float *__restrict__ W1, const float *__restrict__ b1, const float *__restrict__ W2,
+                            const float *__restrict__ b2, const float *__restrict__ w3, const float *__restrict__ b3,
+                            float *__restrict__ packed) {
+    const int gt = blockIdx.x * blockDim.x + threadIdx.x;
+    const int stride = gridDim.x * blockDim.x;
+    // augmented weights: Waug[n][f] = W[n][f] (f < in), b[n] (f == in), 0 otherwise; rows n >= out are 0
+    auto w1aug = [&](int n, int f) { return n < N::H1 ? (f < N::F ? W1[n * N::F + f] : (f == N::F ? b1[n] : 0.f)) : 0.f; };
+    auto w2aug = [&](int n, int f) { return n < N::H2 ? (f < N::H1 ? W2[n * N::H1 + f] : (f == N::H1 ? b2[n] : 0.f)) : 0.f; };
+    for (int e = gt; e < N::NT1 * N::XT * 256; e += stride) {
+        const int s = e & 3, lane = (e >> 2) & 63, tile = e >> 8, To = tile / N::XT, T = tile - To * N::XT;
+        packed[N::W1F_OFF + e] = w1aug(16 * To + (lane & 15), 16 * T + 4 * (lane >> 4) + s);
+    }
+    for (int e = gt; e < N::NT2 * N::H1T * 256; e += stride) {
+        const int s = e & 3, lane = (e >> 2) & 63, tile = e >> 8, To = tile / N::H1T, T = tile - To * N::H1T;
+        packed[N::W2F_OFF + e] = w2aug(16 * To + (lane & 15), 16 * T + 4 * (lane >> 4) + s);
+    }
+    // W2^T fragments for dh1: output tile Ti over fc2 INPUT features, k over fc2 OUTPUT features
+    for (int e = gt; e < N::NT1 * N::NT2 * 256; e += stride) {
+        const int s = e & 3, lane = (e >> 2) & 63, tile = e >> 8, Ti = tile / N::NT2, T = tile - Ti * N::NT2;
+        const int in = 16 * Ti + (lane & 15), o = 16 * T + 4 * (lane >> 4) + s;
+        packed[N::W2T_OFF + e] = (o < N::H2 && in < N::H1) ? W2[o * N::H1 + in] : 0.f;
+    }
+    for (int e = gt; e < N::NT2 * 16 + 16; e += stride)
+        packed[N::W3_OFF + e] = e < N::H2 ? w3[e] : (e == N::NT2 * 16 ? b3[0] : 0.f);
+}
+
+// Sum the per-workgroup partials in a fixed order and scatter into the flat gradient
+// [W1 (H1 x F) | b1 (H1) | W2 (H2 x H1) | b2 (H2) | w3 (H2) | b3 (1)]  (= nn.Module parameter order).
+template <class N>
+__global__ void reduce_grads_kernel(const float *__restrict__ partials, int nparts, float *__restrict__ flat) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= N::NPARAM) return;
+    int off;
+    int k = e;
+    if (k < N::H1 * N::F) {
+        off = N::P_W1 + (k / N::F) * (N::XT * 16) + (k % N::F);
+    } else if ((k -= N::H1 * N::F) < N::H1) {
+        off = N::P_W1 + k * (N::XT * 16) + N::F;
+    } else if ((k -= N::H1) < N::H2 * N::H1) {
+        off = N::P_W2 + (k / N::H1) * (N::H1T * 16) + (k % N::H1);
+    } else if ((k -= N::H2 * N::H1) < N::H2) {
+        off = N::P_W2 + k * (N::H1T * 16) + N::H1;
+    } else if ((k -= N::H2) < N::H2) {
+        off = N::P_W3 + k;
+    } else {
+        off = N::P_B3;
+    }
+    float s = 0.f;
+    for (int p = 0; p < nparts; ++p) s += partials[(size_t)p * N::PART + off];
+    flat[e] = s;
+}
+
+template <class N>
+constexpr size_t pipeline_lds() {
+    return sizeof(float) * (size_t)(kTileDocs * N::LD + 2 * kChunkDocs * N::LD + 5 * kTileDocs + N::NT2 * 16 + 16 +
+                                    kWaves * N::NT2 * 16 + 4 * (128 + 32) + 64);
+}
+
+inline int status() {
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? LTR_OK : (int)e;
+}
+
+template <class N, int MODE>
+int launch_pipeline(const PipeArgs &a, int grid, hipStream_t stream) {
+    constexpr size_t lds = pipeline_lds<N>();
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute((const void *)slate_pipeline_kernel<N, MODE>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+        attr_done = true;
+    }
+    hipLaunchKernelGGL((slate_pipeline_kernel<N, MODE>), dim3(grid), dim3(kThreads), lds, stream, a);
+    return status();
+}
+
+template <class N>
+int pipeline_dispatch(int mode, const PipeArgs &a, int grid, hipStream_t stream) {
+    switch (mode) {
+        case MODE_FWD: return launch_pipeline<N, MODE_FWD>(a, grid, stream);
+        case MODE_BWD: return launch_pipeline<N, MODE_BWD>(a, grid, stream);
+        default: return launch_pipeline<N, MODE_FUSED>(a, grid, stream);
+    }
+}
+
+inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+}  // namespace
+
+extern "C" {
+
+int ltr_net_info(int net, int32_t *info) {
+    if (!info) return LTR_ERR_NULL;
+    if (net == LTR_NET_DOUBLE) {
+        info[0] = DoubleNet::F; info[1] = DoubleNet::H1; info[2] = DoubleNet::H2;
+        info[3] = DoubleNet::NPARAM; info[4] = DoubleNet::PACKED; info[5] = DoubleNet::PART;
+    } else if (net == LTR_NET_TRIPLE) {
+        info[0] = TripleNet::F; info[1] = TripleNet::H1; info[2] = TripleNet::H2;
+        info[3] = TripleNet::NPARAM; info[4] = TripleNet::PACKED; info[5] = TripleNet::PART;
+    } else {
+        return LTR_ERR_PARAM;
+    }
+    info[6] = kTileDocs;
+    info[7] = (int32_t)(net == LTR_NET_DOUBLE ? pipeline_lds<DoubleNet>() : pipeline_lds<TripleNet>());
+    return LTR_OK;
+}
+
+int ltr_mlp_pack(int net, const float *W1, const float *b1, const float *W2, const float *b2, const float *w3,
+                 const float *b3, float *packed, void *stream) {
+    if (!W1 || !b1 || !W2 || !b2 || !w3 || !b3 || !packed) return LTR_ERR_NULL;
+    if (!aligned16(packed)) return LTR_ERR_ALIGN;
+    if (net == LTR_NET_DOUBLE)
+        hipLaunchKernelGGL(pack_kernel<DoubleNet>, dim3(64), dim3(256), 0, (hipStream_t)stream, W1, b1, W2, b2, w3, b3, packed);
+    else if (net == LTR_NET_TRIPLE)
+        hipLaunchKernelGGL(pack_kernel<TripleNet>, dim3(64), dim3(256), 0, (hipStream_t)stream, W1, b1, W2, b2, w3, b3, packed);
+    else
+        return LTR_ERR_PARAM;
+    return status();
+}
+
+static int fill_common(PipeArgs &a, int net, const float *X, int64_t n_docs, const float *packed, int dropout,
+                       uint64_t seed, const uint8_t *keep1, const uint8_t *keep2) {
+    if (!X || !packed) return LTR_ERR_NULL;
+    if (net != LTR_NET_DOUBLE && net != LTR_NET_TRIPLE) return LTR_ERR_PARAM;
+    if (n_docs < 0 || n_docs > ((int64_t)1 << 37)) return LTR_ERR_SHAPE;
+    if (!aligned16(X) || !aligned16(packed)) return LTR_ERR_ALIGN;
+    a = PipeArgs{};
+    a.X = X;
+    a.n_docs = n_docs;
+    a.packed = packed;
+    a.dropout = dropout ? 1 : 0;
+    a.seed = seed;
+    a.keep1 = keep1;
+    a.keep2 = keep2;
+    a.n_super = (int)((n_docs + kTileDocs - 1) / kTileDocs);
+    return LTR_OK;
+}
+
+int ltr_mlp_forward(int net, const float *X, int64_t n_docs, const float *packed, int dropout, uint64_t seed,
+                    const uint8_t *keep1, const uint8_t *keep2, float *scores, int grid, void *stream) {
+    PipeArgs a;
+    if (int rc = fill_common(a, net, X, n_docs, packed, dropout, seed, keep1, keep2)) return rc;
+    if (!scores) return LTR_ERR_NULL;
+    if (grid < 1) return LTR_ERR_PARAM;
+    if (a.n_super == 0) return LTR_OK;
+    a.scores_out = scores;
+    if (grid > a.n_super) grid = a.n_super;
+    return net == LTR_NET_DOUBLE ? pipeline_dispatch<DoubleNet>(MODE_FWD, a, grid, (hipStream_t)stream)
+                                 : pipeline_dispatch<TripleNet>(MODE_FWD, a, grid, (hipStream_t)stream);
+}
+
+int ltr_mlp_backward(int net, const float *X, int64_t n_docs, const float *packed, int dropout, uint64_t seed,
+                     const uint8_t *keep1, const uint8_t *keep2, const float *dscores, float *partials, int grid,
+                     float *flat_grad, void *stream) {
+    PipeArgs a;
+    if (int rc = fill_common(a, net, X, n_docs, packed, dropout, seed, keep1, keep2)) return rc;
+    if (!dscores || !partials || !flat_grad) return LTR_ERR_NULL;
+    if (grid < 1) return LTR_ERR_PARAM;
+    a.dscores_in = dscores;
+    a.partials = partials;
+    int rc;
+    if (net == LTR_NET_DOUBLE) {
+        if ((rc = pipeline_dispatch<DoubleNet>(MODE_BWD, a, grid, (hipStream_t)stream))) return rc;
+        hipLaunchKernelGGL(reduce_grads_kernel<DoubleNet>, dim3((DoubleNet::NPARAM + 255) / 256), dim3(256), 0,
+                           (hipStream_t)stream, partials, grid, flat_grad);
+    } else {
+        if ((rc = pipeline_dispatch<TripleNet>(MODE_BWD, a, grid, (hipStream_t)stream))) return rc;
+        hipLaunchKernelGGL(reduce_grads_kernel<TripleNet>, dim3((TripleNet::NPARAM + 255) / 256), dim3(256), 0,
+                           (hipStream_t)stream, partials, grid, flat_grad);
+    }
+    return status();
+}
+
+int ltr_fused_step(int net, int loss_kind, const float *X, const float *labels, int B, int S, const float *packed,
+                   int dropout, uint64_t seed, const uint8_t *keep1, const uint8_t *keep2, float alpha, float eps,
+                   float pad, int apply_sigmoid, float grad_scale, float *slate_loss, float *partials, int grid,
+                   float *flat_grad, void *stream) {
+    PipeArgs a;
+    if (B < 0 || (S != 32 && S != 64 && S != 128)) return LTR_ERR_SHAPE;
+    if (int rc = fill_common(a, net, X, (int64_t)B * S, packed, dropout, seed, keep1, keep2)) return rc;
+    if (!labels || !slate_loss || !partials || !flat_grad) return LTR_ERR_NULL;
+    if (loss_kind != LTR_LOSS_APPROXNDCG && loss_kind != LTR_LOSS_LISTNET) return LTR_ERR_PARAM;
+    if (grid < 1) return LTR_ERR_PARAM;
+    a.labels = labels;
+    a.B = B;
+    a.S = S;
+    a.slate_loss = slate_loss;
+    a.partials = partials;
+    a.loss_kind = loss_kind;
+    a.alpha = alpha;
+    a.eps = eps;
+    a.pad = pad;
+    a.gscale = grad_scale;
+    a.apply_sigmoid = apply_sigmoid;
+    int rc;
+    if (net == LTR_NET_DOUBLE) {
+        if ((rc = pipeline_dispatch<DoubleNet>(MODE_FUSED, a, grid, (hipStream_t)stream))) return rc;
+        hipLaunchKernelGGL(reduce_grads_kernel<DoubleNet>, dim3((DoubleNet::NPARAM + 255) / 256), dim3(256), 0,
+                           (hipStream_t)stream, partials, grid, flat_grad);
+    } else {
+        if ((rc = pipeline_dispatch<TripleNet>(MODE_FUSED, a, grid, (hipStream_t)stream))) return rc;
+        hipLaunchKernelGGL(reduce_grads_kernel<TripleNet>, dim3((TripleNet::NPARAM + 255) / 256), dim3(256), 0,
+                           (hipStream_t)stream, partials, grid, flat_grad);
+    }
+    return status();
+}
+
+}  // extern "C"

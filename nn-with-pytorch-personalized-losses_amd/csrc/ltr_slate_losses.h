@@ -1,0 +1,306 @@
+// ltr_slate_losses.h -- per-slate listwise losses on LDS-resident slate state (gfx950).
+//
+// Each function is called by ALL threads of a block (uniform barrier count); the threads of one
+// SlateGroup cooperate on one slate whose scores/labels were already staged in LDS.  The same device
+// code serves the standalone loss kernels (ltr_losses.hip) and the fused scorer+loss kernel
+// (ltr_scorer.hip), where the scores never leave the CU.
+//
+// Maths and reference lines: SURVEY.md section 8(a); the closed forms are restated (and pinned against
+// the reference) in oracle/ltr_oracle.py (*_closed_form).
+#pragma once
+#include "ltr_device.h"
+
+namespace ltr {
+
+// Staging convention shared by approxNDCG and lambdaLoss:
+//   sc[j] : score                                   yl[j] : label, -inf if padded (y == pad)
+//   gn[j] : 2^max(y,0) - 1, or -1 if padded         (turned into G_j = gain / maxDCG in place)
+__device__ __forceinline__ void stage_label(float y, float pad, float &yl, float &gn) {
+    bool p = (y == pad);
+    yl = p ? -INFINITY : y;
+    gn = p ? -1.f : (exp2f(fmaxf(y, 0.f)) - 1.f);
+}
+
+// Ideal DCG by rank counting on the labels (approxNDCG.py:28,43 / lambdaL.py:19,39): ties by index.
+// kk > 0 truncates at rank kk.  Returns max(sum, eps) to every thread.
+__device__ __forceinline__ float ideal_dcg(const SlateGroup &g, const float *yl, const float *gn, float eps,
+                                           int kk) {
+    float acc = 0.f;
+    for (int i0 = 0; i0 < g.S; i0 += g.sp) {
+        const int i = i0 + g.ri;
+        const bool row = i < g.S;
+        float cnt = 0.f;
+        if (row) {
+            const float yi = yl[i];
+            for (int j = g.cg; j < g.S; j += g.CG) {
+                const float yj = yl[j];
+                cnt += ((yj > yi) || (yj == yi && j < i)) ? 1.f : 0.f;
+            }
+        }
+        const float r = row_reduce(g, cnt);
+        if (row && g.cg == 0) {
+            const float gi = gn[i];
+            if (gi > 0.f && (kk <= 0 || r < (float)kk)) acc += gi / log2f(2.f + r);
+        }
+    }
+    return fmaxf(group_sum(g, acc), eps);
+}
+
+// ------------------------------------------------------------------------------------------------
+// approxNDCG (losses/approxNDCG.py:7-53).  Returns the slate loss -sum_i G_i / log2(1 + pos_i) to every
+// thread; if want_grad, calls store(i, gscale * dloss/ds_i) once per document (0 for padded documents).
+// gg: LDS [S] scratch.  gn is overwritten with G (padded marker -1 kept).
+template <class Store>
+__device__ __forceinline__ float approx_ndcg_slate(const SlateGroup &g, const float *sc, const float *yl,
+                                                   float *gn, float *gg, float alpha, float eps, float gscale,
+                                                   bool want_grad, Store store) {
+    const float idcg = ideal_dcg(g, yl, gn, eps, 0);
+    __syncthreads();
+    for (int j = g.t; j < g.S; j += g.group) {
+        const float v = gn[j];
+        gn[j] = v < 0.f ? -1.f : v / idcg;
+    }
+    __syncthreads();
+
+    // pos_i = 1 + sum_{j != i, both valid} max(sigmoid(-alpha (s_i - s_j)), eps)            (:47-49)
+    float lossacc = 0.f;
+    for (int i0 = 0; i0 < g.S; i0 += g.sp) {
+        const int i = i0 + g.ri;
+        const bool row = i < g.S;
+        const float si = row ? sc[i] : 0.f;
+        const bool vi = row && gn[i] >= 0.f;
+        float p = 0.f;
+        if (vi) {
+            for (int j = g.cg; j < g.S; j += g.CG) {
+                const float e = __expf(alpha * (si - sc[j]));
+                const float c = fmaxf(__frcp_rn(1.f + e), eps);
+                p += (j != i && gn[j] >= 0.f) ? c : 0.f;
+            }
+        }
+        const float pos = 1.f + row_reduce(g, p);
+        if (row && g.cg == 0) {
+            const float Gi = vi ? gn[i] : 0.f;
+            const float L = log2f(1.f + pos);
+            lossacc += Gi / L;
+            gg[i] = Gi / (L * L * (1.f + pos) * LTR_LN2) * gscale;   // g_i = d loss / d pos_i
+        }
+    }
+    const float total = group_sum(g, lossacc);
+    if (!want_grad) return -total;
+    __syncthreads();  // gg complete
+
+    // d loss / d s_k = alpha * sum_j t_kj (g_j [c_jk >= eps] - g_k [c_kj >= eps]),  t = c_kj c_jk
+    for (int i0 = 0; i0 < g.S; i0 += g.sp) {
+        const int k = i0 + g.ri;
+        const bool row = k < g.S;
+        const float sk = row ? sc[k] : 0.f;
+        const bool vk = row && gn[k] >= 0.f;
+        const float gk = row ? gg[k] : 0.f;
+        float a = 0.f;
+        if (vk) {
+            for (int j = g.cg; j < g.S; j += g.CG) {
+                const float e = __expf(alpha * (sk - sc[j]));
+                const float ckj = __frcp_rn(1.f + e);                 // sigmoid(-alpha (s_k - s_j))
+                const float cjk = (e < 1e30f) ? e * ckj : 1.f;        // sigmoid(-alpha (s_j - s_k))
+                const float term = (cjk >= eps ? gg[j] : 0.f) - (ckj >= eps ? gk : 0.f);
+                a += (j != k && gn[j] >= 0.f) ? ckj * cjk * term : 0.f;
+            }
+        }
+        const float tot = row_reduce(g, a);
+        if (row && g.cg == 0) store(k, vk ? alpha * tot : 0.f);
+    }
+    return -total;
+}
+
+// ------------------------------------------------------------------------------------------------
+// ListNet (losses/listnet.py:5-16).  yt/yp: LDS [S] labels / scores (no padding concept in the reference).
+// Returns -sum_i p_i log q_i (or the apply_sigmoid variant); store(i, gscale * dloss/dscore_i).
+template <class Store>
+__device__ __forceinline__ float listnet_slate(const SlateGroup &g, const float *yt, const float *yp,
+                                               bool apply_sigmoid, float gscale, bool want_grad, Store store) {
+    float my = -INFINITY, ms = -INFINITY;
+    for (int j = g.t; j < g.S; j += g.group) {
+        my = fmaxf(my, yt[j]);
+        ms = fmaxf(ms, yp[j]);
+    }
+    my = group_max(g, my);
+    ms = group_max(g, ms);
+    float zy = 0.f, zs = 0.f;
+    for (int j = g.t; j < g.S; j += g.group) {
+        zy += expf(yt[j] - my);
+        zs += expf(yp[j] - ms);
+    }
+    zy = group_sum(g, zy);
+    zs = group_sum(g, zs);
+    float loss = 0.f, wsum = 0.f;
+    for (int j = g.t; j < g.S; j += g.group) {
+        const float p = expf(yt[j] - my) / zy;
+        const float q = expf(yp[j] - ms) / zs;
+        const float plq = p * logf(q);                // log(softmax) taken literally (:16)
+        if (apply_sigmoid) {
+            const float r = 1.f / (1.f + expf(-plq));
+            loss += r;
+            wsum += r * (1.f - r) * p;
+        } else {
+            loss += plq;
+            wsum += p;
+        }
+    }
+    loss = group_sum(g, loss);
+    if (!want_grad) return -loss;
+    wsum = group_sum(g, wsum);
+    for (int j = g.t; j < g.S; j += g.group) {
+        const float p = expf(yt[j] - my) / zy;
+        const float q = expf(yp[j] - ms) / zs;
+        float w = p;
+        if (apply_sigmoid) {
+            const float r = 1.f / (1.f + expf(-p * logf(q)));
+            w = r * (1.f - r) * p;
+        }
+        store(j, gscale * (q * wsum - w));
+    }
+    return -loss;
+}
+
+// ------------------------------------------------------------------------------------------------
+// LambdaLoss (losses/lambdaL.py:7-127).
+struct LambdaParams {
+    int scheme;      // LTR_SCHEME_*
+    int k;           // <= 0: no truncation
+    float sigma, mu, eps;
+    float log_scale;  // 1/ln2 for binary, 1 for natural: log_b(x) = ln(x) * log_scale
+    float log_floor;  // log_b(eps)
+};
+
+struct LambdaLds {
+    float *sc;     // [S] scores
+    float *yl;     // [S] labels, -inf if padded
+    float *gn;     // [S] gains -> G (padded -1)
+    float *w1;     // [S] G_i / D_{r_i}                  (ndcgLoss1)
+    float *invd;   // [S] 1 / D_{r_i},  D_r = log2(2 + r)
+    float *delta;  // [S] delta_m = |1/D_{m-1} - 1/D_m|, delta_0 = 0      (ndcgLoss2)
+    int *rk;       // [S] 0-based predicted rank of document i
+};
+
+// Rank by counting on the scores (padded documents rank last), G, and the per-document weight inputs.
+__device__ __forceinline__ void lambda_prepare(const SlateGroup &g, const LambdaLds &L, const LambdaParams &P) {
+    const float idcg = ideal_dcg(g, L.yl, L.gn, P.eps, P.k);
+    __syncthreads();
+    for (int j = g.t; j < g.S; j += g.group) {
+        const float v = L.gn[j];
+        L.gn[j] = v < 0.f ? -1.f : v / idcg;
+        // D[m] = log2(m + 2);  delta_m = |1/D[m-1] - 1/D[m]|  (lambdaL.py:100-104)
+        L.delta[j] = j == 0 ? 0.f : fabsf(1.f / log2f((float)j + 1.f) - 1.f / log2f((float)j + 2.f));
+    }
+    __syncthreads();
+    for (int i0 = 0; i0 < g.S; i0 += g.sp) {
+        const int i = i0 + g.ri;
+        const bool row = i < g.S;
+        float cnt = 0.f;
+        if (row) {
+            const bool pi = L.gn[i] < 0.f;
+            const float si = pi ? -INFINITY : L.sc[i];
+            for (int j = g.cg; j < g.S; j += g.CG) {
+                const float sj = L.gn[j] < 0.f ? -INFINITY : L.sc[j];
+                cnt += ((sj > si) || (sj == si && j < i)) ? 1.f : 0.f;
+            }
+        }
+        const float r = row_reduce(g, cnt);
+        if (row && g.cg == 0) {
+            const float D = log2f(2.f + r);
+            L.rk[i] = (int)r;
+            L.invd[i] = 1.f / D;
+            L.w1[i] = fmaxf(L.gn[i], 0.f) / D;
+        }
+    }
+    __syncthreads();
+}
+
+// Pair weight w_ij (first element i, second j), lambdaL.py:96-127.  Gi/Gj are 0 for padded documents.
+template <int SCH>
+__device__ __forceinline__ float lambda_weight(const LambdaLds &L, const LambdaParams &P, int i, int j, float Gi,
+                                               float Gj, float yci, float ycj) {
+    if (SCH == 0 || SCH == 5) return 1.f;
+    if (SCH == 1) return L.w1[i];
+    if (SCH == 6) return fabsf(yci - ycj);
+    if (SCH == 7) return fabsf(yci * yci - ycj * ycj);
+    const float dG = fabsf(Gi - Gj);
+    float w = 0.f;
+    if (SCH == 2 || SCH == 4) {
+        int m = L.rk[i] - L.rk[j];
+        m = m < 0 ? -m : m;
+        w = L.delta[m] * dG;
+        if (SCH == 4) w *= P.mu;
+    }
+    if (SCH == 3 || SCH == 4) w += fabsf(L.invd[i] - L.invd[j]) * dG;
+    return w;
+}
+
+// log_b(clamp(clamp(u, eps)^w, eps)) and d/dx of it w.r.t. x = sigma * d (times sigma later).
+// u = sigmoid(x), um = 1 - u = sigmoid(-x).  live: no clamp active (torch clamp passes grad iff x >= min).
+__device__ __forceinline__ void lambda_pair_term(const LambdaParams &P, float w, float u, float um, float &ell,
+                                                 float &dldx) {
+    const float lg = __logf(fmaxf(u, P.eps)) * P.log_scale;
+    const float wl = w * lg;
+    ell = fmaxf(wl, P.log_floor);
+    const bool live = (u >= P.eps) && (wl >= P.log_floor);
+    dldx = live ? w * um * P.log_scale : 0.f;
+}
+
+// Returns (to every thread) the slate loss -sum_kept ell and writes the kept-pair count to *count_out
+// (every thread gets it); store(i, gscale * dloss/ds_i).
+template <int SCH, class Store>
+__device__ __forceinline__ float lambda_slate(const SlateGroup &g, const LambdaLds &L, const LambdaParams &P,
+                                              float gscale, bool want_grad, float *count_out, Store store) {
+    lambda_prepare(g, L, P);
+    float lossacc = 0.f, cntacc = 0.f;
+    for (int i0 = 0; i0 < g.S; i0 += g.sp) {
+        const int i = i0 + g.ri;
+        const bool row = i < g.S;
+        const bool vi = row && L.gn[i] >= 0.f;
+        float ls = 0.f, cn = 0.f, gr = 0.f;
+        if (vi) {
+            const float si = L.sc[i], yi = L.yl[i], Gi = L.gn[i], yci = fmaxf(yi, 0.f);
+            const bool ki = P.k <= 0 || L.rk[i] < P.k;
+            for (int j = g.cg; j < g.S; j += g.CG) {
+                const float Gj = L.gn[j];
+                const bool ok = ki && Gj >= 0.f && (P.k <= 0 || L.rk[j] < P.k);
+                const float yj = L.yl[j];
+                const float draw = si - L.sc[j];
+                const float d = fminf(fmaxf(draw, -1e8f), 1e8f);
+                const bool dlive = fabsf(draw) <= 1e8f;
+                float u, um;
+                sigmoid_pair(P.sigma * d, u, um);
+                const float ycj = fmaxf(yj, 0.f);
+                // pair (i, j): i first.  ndcgLoss1 keeps every valid pair incl. the diagonal (:26-27).
+                const bool caseA = ok && (SCH == 1 || yi > yj);
+                // pair (j, i): i second (gradient only; its loss term is counted by thread j).
+                const bool caseB = ok && j != i && (SCH == 1 || yj > yi);
+                if (caseA) {
+                    float ell, dl;
+                    lambda_pair_term(P, lambda_weight<SCH>(L, P, i, j, Gi, fmaxf(Gj, 0.f), yci, ycj), u, um, ell, dl);
+                    ls += ell;
+                    cn += 1.f;
+                    gr -= (dlive && j != i) ? dl : 0.f;
+                }
+                if (caseB) {
+                    float ell, dl;
+                    lambda_pair_term(P, lambda_weight<SCH>(L, P, j, i, fmaxf(Gj, 0.f), Gi, ycj, yci), um, u, ell, dl);
+                    gr += dlive ? dl : 0.f;
+                }
+            }
+        }
+        lossacc += row_reduce(g, ls);     // every cg replica adds the same row total ...
+        cntacc += row_reduce(g, cn);
+        if (want_grad) {
+            const float tot = row_reduce(g, gr);
+            if (row && g.cg == 0) store(i, vi ? gscale * P.sigma * tot : 0.f);
+        }
+    }
+    // ... so count each row once: only column group 0 contributes to the group total.
+    const float total = group_sum(g, g.cg == 0 ? lossacc : 0.f);
+    *count_out = group_sum(g, g.cg == 0 ? cntacc : 0.f);
+    return -total;
+}
+
+}  // namespace ltr

@@ -1,0 +1,75 @@
+"""ctypes binding of libltr_mi355x.so (the C ABI declared in include/ltr_mi355x.h)."""
+import ctypes
+import os
+from ctypes import c_char_p, c_float, c_int, c_int64, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "libltr_mi355x.so")
+
+
+class LtrError(RuntimeError):
+    """A launcher returned non-zero (argument rejected or hipError_t)."""
+
+
+class LtrBuildError(LtrError):
+    """libltr_mi355x.so is missing / not loadable: the HIP path is the only path, so this is fatal."""
+
+
+class LtrDeviceError(LtrError):
+    """An op was handed a tensor that does not live on a ROCm device."""
+
+
+P = c_void_p
+_PROTOTYPES = {
+    "ltr_abi_version": (c_int, []),
+    "ltr_error_string": (c_char_p, [c_int]),
+    "ltr_reduce_sum_f32": (c_int, [P, c_int64, c_float, P, P]),
+    "ltr_approxndcg_fwd_bwd": (c_int, [P, P, c_int, c_int, c_float, c_float, c_float, c_float, P, P, P]),
+    "ltr_listnet_fwd_bwd": (c_int, [P, P, c_int, c_int, c_int, c_float, P, P, P]),
+    "ltr_lambda_fwd_bwd": (c_int, [P, P, c_int, c_int, c_int, c_int, c_float, c_float, c_float, c_float, c_int,
+                                   c_float, P, P, P, P]),
+    "ltr_lambda_pairs_fwd": (c_int, [P, P, c_int, c_int, c_int, c_int, c_float, c_float, c_float, c_float, c_int,
+                                     P, P, P, P]),
+    "ltr_lambda_pairs_bwd": (c_int, [P, P, c_int, c_int, c_int, c_int, c_float, c_float, c_float, c_float, c_int,
+                                     P, P, P]),
+    "ltr_ordinal_num_blocks": (c_int64, [c_int64]),
+    "ltr_ordinal_fwd_bwd": (c_int, [P, P, c_int64, c_int, c_float, P, P, P, P]),
+}
+
+_lib = None
+
+
+def library_path():
+    return _SO
+
+
+def lib():
+    """Load (once) and return the ctypes handle.  Raises LtrBuildError if the library is not built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_SO):
+            raise LtrBuildError(
+                f"{_SO} not found: build the HIP extension first (python -c 'import __graft_entry__ as g; "
+                "g.build()' at the repo root).  There is no CPU fallback.")
+        try:
+            h = ctypes.CDLL(_SO)
+        except OSError as e:  # pragma: no cover - depends on the box
+            raise LtrBuildError(f"cannot load {_SO}: {e}") from e
+        for name, (res, args) in _PROTOTYPES.items():
+            try:
+                fn = getattr(h, name)
+            except AttributeError as e:
+                raise LtrBuildError(f"{_SO} does not export {name}: stale build?") from e
+            fn.restype = res
+            fn.argtypes = args
+        from . import _scorer_protos
+        _scorer_protos.bind(h)
+        if h.ltr_abi_version() != 1:
+            raise LtrBuildError(f"{_SO}: ABI version {h.ltr_abi_version()} != 1")
+        _lib = h
+    return _lib
+
+
+def check(rc, what):
+    if rc != 0:
+        raise LtrError(f"{what}: {lib().ltr_error_string(rc).decode()} (code {rc})")
