@@ -1,0 +1,195 @@
+#!/usr/bin/env python3
+"""Headline benchmark: slates/s, forward+backward(+optimizer), approxNDCG + DoubleLayerNet, slate 128 x 136
+features, fp32, synthetic MSLR-WEB30K-shaped data resident in HBM (BASELINE.json configs[1]).
+
+  python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run)
+
+A step = one optimizer step of the query-sharded trainer on `--batch` slates per GPU: ONE fused launch
+(scorer fwd -> approxNDCG -> scorer bwd -> weight gradients), a fixed-order gradient reduce, one all-reduce
+of the flat [grads | loss] buffer (N > 1) and a fused Adam update.  Per-GPU work is fixed as N grows (weak).
+Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel (the fused slate pipeline), timed
+with HIP events on its own stream inside the timed region; `cpu_baseline` is the oracle's op-level
+restatement of the reference's CPU path, timed on this box's host cores (rank 0, N = 1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "nn-with-pytorch-personalized-losses_amd"))
+
+F = 136
+PEAK_HBM_GBPS = 8000.0          # MI355X HBM3E spec (MI355X_MICROARCH.md); 6290 measured float4 copy
+PEAK_HBM_MEASURED_GBPS = 6290.0
+PEAK_F32_MFMA_TFLOPS = 157.3    # dense fp32 MFMA (= fp32 vector) peak
+
+
+def flops_per_doc(net):
+    """Algorithmic FLOPs fwd + bwd (no dX), SURVEY.md section 8(a)/(d)."""
+    if net == "double":
+        mac = (136 * 136 * 2 + 136) + (136 * 136 * 3 + 136 * 2)      # 92 888
+    else:
+        mac = (136 * 64 + 64 * 32 + 32) + (136 * 64 + 64 * 32 * 2 + 32 * 2)
+    return 2.0 * mac
+
+
+def synth(Q, S, device, seed):
+    """X ~ N(0,1) (MSLR 'Norm' features are per-query normalised), grades with MSLR-like skew."""
+    gen = torch.Generator(device=device).manual_seed(seed)
+    X = torch.empty((Q, S, F), dtype=torch.float32, device=device)
+    step = max(1, 8192 // max(S // 32, 1))
+    for i in range(0, Q, step):
+        X[i:i + step].normal_(generator=gen)
+    p = torch.tensor([0.52, 0.32, 0.13, 0.02, 0.01], device=device)
+    y = torch.multinomial(p, Q * S, replacement=True, generator=gen).view(Q, S).float()
+    return X, y
+
+
+def cpu_baseline(net_kind, S, budget_s=12.0):
+    """The reference's CPU path as restated by the oracle (torch CPU ops + autograd, [B,S,S] intermediates),
+    B = 200 slates per step (main.py:59), timed on this box's host cores."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import ltr_oracle as O   # the timed CPU baseline ("port"), never part of the product path
+    torch.manual_seed(2020)
+    B = 200
+    if net_kind == "double":
+        shapes = {"fc1.weight": (136, 136), "fc1.bias": (136,), "fc2.weight": (136, 136), "fc2.bias": (136,),
+                  "fc3.weight": (1, 136), "fc3.bias": (1,)}
+    else:
+        shapes = {"l1.weight": (64, 136), "l1.bias": (64,), "l2.weight": (32, 64), "l2.bias": (32,),
+                  "l3.weight": (1, 32), "l3.bias": (1,)}
+    p = {k: (torch.randn(v) * 0.05).requires_grad_(True) for k, v in shapes.items()}
+    opt = torch.optim.Adam(list(p.values()), lr=1e-3)
+    x = torch.randn(B, S, F)
+    y = torch.randint(0, 5, (B, S)).float()
+
+    def one():
+        opt.zero_grad()
+        if net_kind == "double":
+            k1 = (torch.rand(B, S, 136) < 0.5).float()
+            k2 = (torch.rand(B, S, 136) < 0.5).float()
+            s = O.double_layer_forward(x, p, k1, k2)
+        else:
+            s = O.triple_layer_forward(x, p)
+        loss = O.approx_ndcg(s.squeeze(-1), y)
+        loss.backward()
+        opt.step()
+
+    one()
+    t0 = time.perf_counter()
+    n = 0
+    while time.perf_counter() - t0 < budget_s:
+        one()
+        n += 1
+    dt = time.perf_counter() - t0
+    return {"value": round(B * n / dt, 1), "unit": "slates/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{n} steps of B=200 x S={S} x F=136 ({net_kind}LayerNet + approxNDCG + Adam, fp32) in {dt:.1f}s; "
+                      "oracle restatement of the reference's torch-CPU path (no dX, unlike the reference)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--warmup", type=int, default=4)
+    ap.add_argument("--queries", type=int, default=100_000, help="resident queries per GPU")
+    ap.add_argument("--slate", type=int, default=128)
+    ap.add_argument("--batch", type=int, default=25_000, help="slates per GPU per step")
+    ap.add_argument("--net", choices=["double", "triple"], default="double")
+    ap.add_argument("--eval-mode", action="store_true", help="no dropout (default: training mode, like the reference loop)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    a = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != a.gpus:
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {a.gpus}")
+    import torch.distributed as dist
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from architeture.doubleLayer import DoubleLayerNet
+    from architeture.tripleLayer import TripleLayerNet
+    from ltr_mi355x.dp import QueryShardedTrainer, sync_parameters
+    from ltr_mi355x.scorer import FusedRanker
+
+    torch.manual_seed(2020)
+    net = (DoubleLayerNet(F) if a.net == "double" else TripleLayerNet(F)).to(dev)
+    net.train(not a.eval_mode)
+    sync_parameters(net)
+    Q, S, B = a.queries, a.slate, min(a.batch, a.queries)
+    X, y = synth(Q, S, dev, 2020 + rank)
+    ranker = FusedRanker(net, loss="approxNDCG")
+    ranker.seed_salt = rank
+    opt = torch.optim.Adam(net.parameters(), lr=1e-3, fused=True)
+    trainer = QueryShardedTrainer(ranker, opt)
+    n_win = max(1, Q // B)
+
+    def step(i):
+        lo = (i % n_win) * B
+        return trainer.step(X[lo:lo + B], y[lo:lo + B])
+
+    for i in range(a.warmup):
+        step(i)
+    # --- timed region: barrier + synchronize on both sides, max over ranks
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(a.steps)]
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(a.steps):
+        ranker.kernel_events = evs[i]
+        loss = step(a.warmup + i)
+    ranker.kernel_events = None
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    dt = float(tt)
+    kern_ms = sum(s.elapsed_time(e) for s, e in evs) / a.steps
+    final_loss = float(loss)
+
+    if rank == 0:
+        slates_per_s = world * B * a.steps / dt
+        fl_slate = flops_per_doc(a.net) * S
+        by_slate = S * (F + 1) * 4
+        ach_tf = fl_slate * B / (kern_ms * 1e-3) / 1e12
+        ach_gb = by_slate * B / (kern_ms * 1e-3) / 1e9
+        out = {
+            "metric": "slates/sec fwd+bwd approxNDCG slate=128 feat=136",
+            "value": round(slates_per_s, 1), "unit": "slates/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": round(dt / a.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"approxNDCG + {a.net}LayerNet ({'136-136-136-1' if a.net == 'double' else '136-64-32-1'}) "
+                                   f"{'train-mode dropout' if net.training and a.net == 'double' else 'no dropout'}, "
+                                   f"{Q} queries x slate {S} x {F} feat fp32 per GPU resident in HBM, "
+                                   f"{B} slates per GPU per step, fused fwd+loss+bwd + grad all-reduce + Adam",
+                       "queries_per_gpu": Q, "slate": S, "features": F, "batch_per_gpu": B, "net": a.net,
+                       "parallelism": f"query-sharded dp{world}", "final_loss": round(final_loss, 6)},
+            "roofline": {"bound": "mfma", "achieved": round(ach_tf, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                         "frac": round(ach_tf / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+                         "kernel": "slate_pipeline_kernel<MODE_FUSED>", "kernel_ms": round(kern_ms, 4),
+                         "flops_per_slate": fl_slate, "bytes_per_slate": by_slate,
+                         "hbm_achieved_GBps": round(ach_gb, 1), "hbm_frac_of_8TBps": round(ach_gb / PEAK_HBM_GBPS, 4),
+                         "hbm_frac_of_measured_copy": round(ach_gb / PEAK_HBM_MEASURED_GBPS, 4)},
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(a.net, S)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -102,6 +102,60 @@ int64_t ltr_ordinal_num_blocks(int64_t n_docs);
 int ltr_ordinal_fwd_bwd(const float *y_pred, const float *y_true, int64_t n_docs, int n, float pad,
                         float *block_partials, float *sums, float *dpred, void *stream);
 
+/* =====================================================================================================
+ * FC scorers and the fused slate pipeline (scorer forward -> listwise loss -> scorer backward -> dW).
+ *
+ *   LTR_NET_DOUBLE  architeture/doubleLayer.py:54-73  fc3(drop(relu(fc2(drop(relu(fc1 x))))))  136-136-136-1
+ *   LTR_NET_TRIPLE  architeture/tripleLayer.py:5-17   l3(sigmoid(l2(l1 x)))                     136-64-32-1
+ *
+ * Parameters are handed over exactly as the nn.Module holds them (nn.Linear: weight [out][in], bias [out]);
+ * ltr_mlp_pack turns them into lane-ordered MFMA fragments once per optimizer step.  X is [n_docs][F]
+ * fp32, 16-byte aligned, documents of a slate contiguous ([B][S][F] viewed as [B*S][F]).
+ * Gradients come back as ONE flat fp32 buffer in nn.Module.parameters() order
+ *   [W1 (H1*F) | b1 (H1) | W2 (H2*H1) | b2 (H2) | w3 (H2) | b3 (1)]
+ * -- the buffer the data-parallel all-reduce runs on.  No gradient w.r.t. X is produced (the reference
+ * computes one only because its drivers set requires_grad on the data, main_batch_execution.py:79).
+ */
+enum { LTR_NET_DOUBLE = 0, LTR_NET_TRIPLE = 1 };
+enum { LTR_LOSS_APPROXNDCG = 0, LTR_LOSS_LISTNET = 1 };
+
+/* info[0..7] = F, H1, H2, n_params, packed_floats, partial_floats (per workgroup), docs_per_tile, lds_bytes */
+int ltr_net_info(int net, int32_t *info);
+
+int ltr_mlp_pack(int net, const float *W1, const float *b1, const float *W2, const float *b2, const float *w3,
+                 const float *b3, float *packed, void *stream);
+
+/* Scorer forward: scores[n_docs] = net(X).  dropout != 0 applies training-mode Dropout(0.5) after each ReLU
+ * (doubleLayer.py:60-65) from the counter-based stream (seed, document, feature); keep1/keep2, when non-NULL,
+ * are explicit keep masks [n_docs][H1] / [n_docs][H2] (bytes, != 0 keeps) used INSTEAD of the generator
+ * (parity tests).  grid = number of persistent workgroups (normally the CU count). */
+int ltr_mlp_forward(int net, const float *X, int64_t n_docs, const float *packed, int dropout, uint64_t seed,
+                    const uint8_t *keep1, const uint8_t *keep2, float *scores, int grid, void *stream);
+
+/* out[doc][n] (bytes, n < H) = keep bit of dropout layer `layer` (0 after fc1, 1 after fc2) that the pipeline
+ * kernels derive from (seed, document index, feature index): the counter-based replacement for the torch
+ * CPU generator stream behind nn.Dropout (doubleLayer.py:60), which cannot be reproduced on the device. */
+int ltr_dropout_keep_mask(uint64_t seed, int layer, int64_t n_docs, int H, uint8_t *out, void *stream);
+
+/* Scorer backward given dL/dscores[n_docs]: recomputes the forward from X (same seed/masks) and leaves one
+ * gradient partial per workgroup in `partials` (grid * partial_floats floats); ltr_mlp_reduce_grads then sums
+ * them in a fixed order into the flat parameter gradient. */
+int ltr_mlp_backward(int net, const float *X, int64_t n_docs, const float *packed, int dropout, uint64_t seed,
+                     const uint8_t *keep1, const uint8_t *keep2, const float *dscores, float *partials, int grid,
+                     void *stream);
+int ltr_mlp_reduce_grads(int net, const float *partials, int grid, float *flat_grad, void *stream);
+
+/* One fused training pass over B slates of S documents (S in {32, 64, 128}): scorer forward, per-slate loss
+ * (LTR_LOSS_*; labels [B][S]), loss backward, scorer backward -- scores never leave the CU, X is read once.
+ *   slate_loss[b]  : per-slate loss (caller reduces: mean for approxNDCG, sum for ListNet)
+ *   partials       : per-workgroup partials of d (sum_b grad_scale * slate_loss[b]) / d params, to be summed by
+ *                    ltr_mlp_reduce_grads (grad_scale = 1/B_global for a mean)
+ * main_batch_execution.py:128-170 is the reference call chain this replaces. */
+int ltr_fused_step(int net, int loss_kind, const float *X, const float *labels, int B, int S, const float *packed,
+                   int dropout, uint64_t seed, const uint8_t *keep1, const uint8_t *keep2, float alpha, float eps,
+                   float pad, int apply_sigmoid, float grad_scale, float *slate_loss, float *partials, int grid,
+                   void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -125,6 +125,9 @@ __device__ __forceinline__ void gemm_wx(const f32x4 *__restrict__ wf, int lane, 
         }
         out[0][To] = c0;
         out[1][To] = c1;
+        // one scheduling region per output tile: stops hipcc hoisting all NT*KT fragment loads to the top
+        // of the (fully unrolled) GEMM, which costs > 300 VGPRs and spills
+        __builtin_amdgcn_sched_barrier(0);
     }
 }
 
@@ -341,7 +344,9 @@ __global__ void __launch_bounds__(kThreads, 1) slate_pipeline_kernel(const PipeA
         __syncthreads();
 
         // ---- backward through fc3: dw3 += ds * h2 (sum over documents = lanes d), dz2 = ds * w3 * act2'(h2)
-        const float ds0 = dsc[32 * w + d], ds1 = dsc[32 * w + 16 + d];
+        // documents past the end of the batch must not contribute to any gradient
+        const float ds0 = gdoc0 < a.n_docs ? dsc[32 * w + d] : 0.f;
+        const float ds1 = gdoc1 < a.n_docs ? dsc[32 * w + 16 + d] : 0.f;
         {
             float sb = (q == 0) ? ds0 + ds1 : 0.f;
             db3 += wave_allsum(sb);
@@ -433,6 +438,15 @@ __global__ void __launch_bounds__(kThreads, 1) slate_pipeline_kernel(const PipeA
     if (lane == 0) scratch[w] = db3;
     __syncthreads();
     if (tid == 0) part[N::P_B3] = scratch[0] + scratch[1] + scratch[2] + scratch[3];
+}
+
+// The keep mask the pipeline's counter-based dropout stream produces (tests / reproducibility tooling).
+__global__ void dropout_mask_kernel(unsigned long long seed, int layer, long long n_docs, int H, uint8_t *out) {
+    const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n_docs * H) return;
+    const long long doc = e / H;
+    const int n = (int)(e - doc * H);
+    out[e] = (keep_word(seed, layer, doc, n >> 5) >> (n & 31)) & 1u;
 }
 
 // Pack nn.Linear parameters into lane-ordered MFMA A-fragments (once per optimizer step; 37k params).
@@ -545,6 +559,16 @@ int ltr_net_info(int net, int32_t *info) {
     return LTR_OK;
 }
 
+int ltr_dropout_keep_mask(uint64_t seed, int layer, int64_t n_docs, int H, uint8_t *out, void *stream) {
+    if (!out) return LTR_ERR_NULL;
+    if (n_docs < 0 || H < 1 || H > 4096 || layer < 0 || layer > 1) return LTR_ERR_SHAPE;
+    const long long n = n_docs * H;
+    if (n == 0) return LTR_OK;
+    hipLaunchKernelGGL(dropout_mask_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, seed,
+                       layer, (long long)n_docs, H, out);
+    return status();
+}
+
 int ltr_mlp_pack(int net, const float *W1, const float *b1, const float *W2, const float *b2, const float *w3,
                  const float *b3, float *packed, void *stream) {
     if (!W1 || !b1 || !W2 || !b2 || !w3 || !b3 || !packed) return LTR_ERR_NULL;
@@ -591,34 +615,39 @@ int ltr_mlp_forward(int net, const float *X, int64_t n_docs, const float *packed
 
 int ltr_mlp_backward(int net, const float *X, int64_t n_docs, const float *packed, int dropout, uint64_t seed,
                      const uint8_t *keep1, const uint8_t *keep2, const float *dscores, float *partials, int grid,
-                     float *flat_grad, void *stream) {
+                     void *stream) {
     PipeArgs a;
     if (int rc = fill_common(a, net, X, n_docs, packed, dropout, seed, keep1, keep2)) return rc;
-    if (!dscores || !partials || !flat_grad) return LTR_ERR_NULL;
+    if (!dscores || !partials) return LTR_ERR_NULL;
     if (grid < 1) return LTR_ERR_PARAM;
     a.dscores_in = dscores;
     a.partials = partials;
-    int rc;
-    if (net == LTR_NET_DOUBLE) {
-        if ((rc = pipeline_dispatch<DoubleNet>(MODE_BWD, a, grid, (hipStream_t)stream))) return rc;
+    return net == LTR_NET_DOUBLE ? pipeline_dispatch<DoubleNet>(MODE_BWD, a, grid, (hipStream_t)stream)
+                                 : pipeline_dispatch<TripleNet>(MODE_BWD, a, grid, (hipStream_t)stream);
+}
+
+int ltr_mlp_reduce_grads(int net, const float *partials, int grid, float *flat_grad, void *stream) {
+    if (!partials || !flat_grad) return LTR_ERR_NULL;
+    if (grid < 1) return LTR_ERR_PARAM;
+    if (net == LTR_NET_DOUBLE)
         hipLaunchKernelGGL(reduce_grads_kernel<DoubleNet>, dim3((DoubleNet::NPARAM + 255) / 256), dim3(256), 0,
                            (hipStream_t)stream, partials, grid, flat_grad);
-    } else {
-        if ((rc = pipeline_dispatch<TripleNet>(MODE_BWD, a, grid, (hipStream_t)stream))) return rc;
+    else if (net == LTR_NET_TRIPLE)
         hipLaunchKernelGGL(reduce_grads_kernel<TripleNet>, dim3((TripleNet::NPARAM + 255) / 256), dim3(256), 0,
                            (hipStream_t)stream, partials, grid, flat_grad);
-    }
+    else
+        return LTR_ERR_PARAM;
     return status();
 }
 
 int ltr_fused_step(int net, int loss_kind, const float *X, const float *labels, int B, int S, const float *packed,
                    int dropout, uint64_t seed, const uint8_t *keep1, const uint8_t *keep2, float alpha, float eps,
                    float pad, int apply_sigmoid, float grad_scale, float *slate_loss, float *partials, int grid,
-                   float *flat_grad, void *stream) {
+                   void *stream) {
     PipeArgs a;
     if (B < 0 || (S != 32 && S != 64 && S != 128)) return LTR_ERR_SHAPE;
     if (int rc = fill_common(a, net, X, (int64_t)B * S, packed, dropout, seed, keep1, keep2)) return rc;
-    if (!labels || !slate_loss || !partials || !flat_grad) return LTR_ERR_NULL;
+    if (!labels || !slate_loss || !partials) return LTR_ERR_NULL;
     if (loss_kind != LTR_LOSS_APPROXNDCG && loss_kind != LTR_LOSS_LISTNET) return LTR_ERR_PARAM;
     if (grid < 1) return LTR_ERR_PARAM;
     a.labels = labels;
@@ -632,17 +661,8 @@ int ltr_fused_step(int net, int loss_kind, const float *X, const float *labels, 
     a.pad = pad;
     a.gscale = grad_scale;
     a.apply_sigmoid = apply_sigmoid;
-    int rc;
-    if (net == LTR_NET_DOUBLE) {
-        if ((rc = pipeline_dispatch<DoubleNet>(MODE_FUSED, a, grid, (hipStream_t)stream))) return rc;
-        hipLaunchKernelGGL(reduce_grads_kernel<DoubleNet>, dim3((DoubleNet::NPARAM + 255) / 256), dim3(256), 0,
-                           (hipStream_t)stream, partials, grid, flat_grad);
-    } else {
-        if ((rc = pipeline_dispatch<TripleNet>(MODE_FUSED, a, grid, (hipStream_t)stream))) return rc;
-        hipLaunchKernelGGL(reduce_grads_kernel<TripleNet>, dim3((TripleNet::NPARAM + 255) / 256), dim3(256), 0,
-                           (hipStream_t)stream, partials, grid, flat_grad);
-    }
-    return status();
+    return net == LTR_NET_DOUBLE ? pipeline_dispatch<DoubleNet>(MODE_FUSED, a, grid, (hipStream_t)stream)
+                                 : pipeline_dispatch<TripleNet>(MODE_FUSED, a, grid, (hipStream_t)stream);
 }
 
 }  // extern "C"

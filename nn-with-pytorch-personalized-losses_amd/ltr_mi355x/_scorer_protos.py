@@ -2,7 +2,16 @@
 from ctypes import c_float, c_int, c_int64, c_uint64, c_void_p
 
 P = c_void_p
-PROTOTYPES = {}
+PROTOTYPES = {
+    "ltr_net_info": (c_int, [c_int, P]),
+    "ltr_mlp_pack": (c_int, [c_int, P, P, P, P, P, P, P, P]),
+    "ltr_dropout_keep_mask": (c_int, [c_uint64, c_int, c_int64, c_int, P, P]),
+    "ltr_mlp_forward": (c_int, [c_int, P, c_int64, P, c_int, c_uint64, P, P, P, c_int, P]),
+    "ltr_mlp_backward": (c_int, [c_int, P, c_int64, P, c_int, c_uint64, P, P, P, P, c_int, P]),
+    "ltr_mlp_reduce_grads": (c_int, [c_int, P, c_int, P, P]),
+    "ltr_fused_step": (c_int, [c_int, c_int, P, P, c_int, c_int, P, c_int, c_uint64, P, P, c_float, c_float, c_float,
+                               c_int, c_float, P, P, c_int, P]),
+}
 
 
 def bind(h):

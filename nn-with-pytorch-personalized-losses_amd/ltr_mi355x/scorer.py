@@ -1,0 +1,239 @@
+"""Host side of the slate pipeline (csrc/ltr_scorer.hip): FC scorers and the fused training pass.
+
+Two ways in, same kernels:
+  * `mlp_scores(module, x, ...)` -- the nn.Module path (`net(x, None, None)` like the reference,
+    main_batch_execution.py:128): forward launch now, backward launch when autograd asks for it
+    (the forward is recomputed from X inside the backward launch; activations are never stored in HBM).
+  * `FusedRanker.step(...)`      -- scorer forward + listwise loss + backward + weight gradients in ONE
+    launch over a batch of slates; gradients land in one flat buffer that aliases every `param.grad`
+    (the buffer the data-parallel all-reduce runs on).
+"""
+import ctypes
+
+import torch
+
+from ._lib import LtrError, check, lib
+from .functional import _ptr, _stream, require_device
+
+NET_DOUBLE, NET_TRIPLE = 0, 1
+LOSS_APPROXNDCG, LOSS_LISTNET = 0, 1
+_MASK64 = (1 << 64) - 1
+
+
+class NetInfo:
+    """Static geometry of a compiled network (ltr_net_info)."""
+    _cache = {}
+
+    def __init__(self, net):
+        buf = (ctypes.c_int32 * 8)()
+        check(lib().ltr_net_info(net, buf), "ltr_net_info")
+        (self.F, self.H1, self.H2, self.n_params, self.packed_floats, self.partial_floats, self.tile_docs,
+         self.lds_bytes) = list(buf)
+        self.net = net
+        self.shapes = [(self.H1, self.F), (self.H1,), (self.H2, self.H1), (self.H2,), (1, self.H2), (1,)]
+
+    @classmethod
+    def get(cls, net):
+        if net not in cls._cache:
+            cls._cache[net] = cls(net)
+        return cls._cache[net]
+
+
+def cu_count(device):
+    return torch.cuda.get_device_properties(device).multi_processor_count
+
+
+def default_grid(device, n_docs, tile_docs=128):
+    """Persistent workgroups: one per CU, never more than there are 128-document tiles."""
+    return max(1, min(cu_count(device), (n_docs + tile_docs - 1) // tile_docs))
+
+
+def next_seed(counter):
+    """Dropout stream seed: torch's global seed mixed with a per-call counter (no device sync)."""
+    return (torch.initial_seed() * 0x9E3779B97F4A7C15 + counter * 0xD1B54A32D192ED03 + 0x8CB92BA72F3D8DD7) & _MASK64
+
+
+def _params_f32(params):
+    out = []
+    for p in params:
+        t = p.detach()
+        if t.dtype != torch.float32 or not t.is_contiguous():
+            t = t.to(torch.float32).contiguous()
+        out.append(t)
+    return out
+
+
+def pack_params(net, params, out=None):
+    """nn.Linear weights/biases [W1,b1,W2,b2,w3,b3] -> lane-ordered MFMA fragments (ltr_mlp_pack)."""
+    info = NetInfo.get(net)
+    ps = _params_f32(params)
+    for t, shape in zip(ps, info.shapes):
+        if tuple(t.shape) != shape:
+            raise ValueError(f"parameter shape {tuple(t.shape)} != expected {shape}")
+    dev = ps[0].device
+    if out is None:
+        out = torch.empty(info.packed_floats, dtype=torch.float32, device=dev)
+    check(lib().ltr_mlp_pack(net, *[_ptr(t) for t in ps], _ptr(out), _stream()), "ltr_mlp_pack")
+    return out
+
+
+def _docs(x, info):
+    if x.dim() < 2 or x.shape[-1] != info.F:
+        raise ValueError(f"expected [..., {info.F}] features, got {tuple(x.shape)}")
+    if x.dtype != torch.float32:
+        raise TypeError(f"scorer kernels take fp32 features, got {x.dtype}")
+    x2 = x.detach().reshape(-1, info.F)
+    if not x2.is_contiguous():
+        x2 = x2.contiguous()
+    if x2.data_ptr() % 16:
+        x2 = x2.clone()
+    return x2
+
+
+def _mask(m, n_docs, H):
+    if m is None:
+        return None
+    m = m.detach().reshape(n_docs, H).to(torch.uint8).contiguous()
+    return m
+
+
+class _MLPScores(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, net, dropout, seed, keep1, keep2, *params):
+        info = NetInfo.get(net)
+        dev = x.device
+        with torch.cuda.device(dev):
+            x2 = _docs(x, info)
+            n = x2.shape[0]
+            packed = pack_params(net, params)
+            k1, k2 = _mask(keep1, n, info.H1), _mask(keep2, n, info.H2)
+            scores = torch.empty(n, dtype=torch.float32, device=dev)
+            grid = default_grid(dev, n, info.tile_docs)
+            check(lib().ltr_mlp_forward(net, _ptr(x2), n, _ptr(packed), int(dropout), seed, _ptr(k1), _ptr(k2),
+                                        _ptr(scores), grid, _stream()), "ltr_mlp_forward")
+        ctx.save_for_backward(x2, packed, k1, k2)
+        ctx.meta = (net, int(dropout), seed, grid, [p.dtype for p in params])
+        return scores.view(*x.shape[:-1], 1)
+
+    @staticmethod
+    def backward(ctx, g):
+        x2, packed, k1, k2 = ctx.saved_tensors
+        net, dropout, seed, grid, dtypes = ctx.meta
+        info = NetInfo.get(net)
+        dev = x2.device
+        n = x2.shape[0]
+        with torch.cuda.device(dev):
+            gs = g.detach().reshape(-1).to(torch.float32).contiguous()
+            partials = torch.empty(grid * info.partial_floats, dtype=torch.float32, device=dev)
+            flat = torch.empty(info.n_params, dtype=torch.float32, device=dev)
+            check(lib().ltr_mlp_backward(net, _ptr(x2), n, _ptr(packed), dropout, seed, _ptr(k1), _ptr(k2), _ptr(gs),
+                                         _ptr(partials), grid, _stream()), "ltr_mlp_backward")
+            check(lib().ltr_mlp_reduce_grads(net, _ptr(partials), grid, _ptr(flat), _stream()), "ltr_mlp_reduce_grads")
+        grads, off = [], 0
+        for shape, dt in zip(info.shapes, dtypes):
+            cnt = 1
+            for s in shape:
+                cnt *= s
+            grads.append(flat[off:off + cnt].view(shape).to(dt))
+            off += cnt
+        return (None, None, None, None, None, None) + tuple(grads)
+
+
+def mlp_scores(net, params, x, dropout=False, seed=0, keep1=None, keep2=None):
+    """scores[..., 1] = net(x) on the device.  x: [..., F] fp32 device tensor.  No gradient w.r.t. x."""
+    require_device(x, *params)
+    return _MLPScores.apply(x, net, bool(dropout), int(seed), keep1, keep2, *params)
+
+
+def dropout_keep_mask(seed, layer, n_docs, H, device):
+    out = torch.empty((n_docs, H), dtype=torch.uint8, device=device)
+    with torch.cuda.device(device):
+        check(lib().ltr_dropout_keep_mask(int(seed) & _MASK64, layer, n_docs, H, _ptr(out), _stream()),
+              "ltr_dropout_keep_mask")
+    return out
+
+
+class FusedRanker:
+    """One-launch training pass for a DoubleLayerNet / TripleLayerNet with a listwise loss.
+
+        ranker = FusedRanker(net, loss="approxNDCG")
+        loss = ranker.step(X, y)          # X [B,S,F] fp32 device, y [B,S]; fills p.grad for every parameter
+        opt.step()
+
+    Equivalent to `loss = lossfn(net(X, None, None).squeeze(-1), y); loss.backward()` of the reference loop
+    (main_batch_execution.py:128-170), with X read from HBM once and nothing but the loss written back.
+    `flat_grad` is a single fp32 buffer that every `param.grad` aliases: one all-reduce for data parallel.
+    `grad_div` rescales the mean-type losses for a global batch (B_global = B * world_size).
+    """
+
+    LOSSES = {"approxNDCG": LOSS_APPROXNDCG, "listnet": LOSS_LISTNET}
+
+    def __init__(self, module, loss="approxNDCG", alpha=1.0, eps=1e-10, padded_value_indicator=-1,
+                 apply_sigmoid=False, grid=None):
+        if loss not in self.LOSSES:
+            raise KeyError(f"fused loss must be one of {sorted(self.LOSSES)}, got {loss!r}")
+        self.module = module
+        self.net = module._ltr_net
+        self.info = NetInfo.get(self.net)
+        self.loss = loss
+        self.loss_kind = self.LOSSES[loss]
+        self.alpha, self.eps, self.pad = float(alpha), float(eps), float(padded_value_indicator)
+        self.apply_sigmoid = bool(apply_sigmoid)
+        self.params = module._ltr_params()
+        require_device(*self.params)
+        dev = self.params[0].device
+        self.device = dev
+        self.grid = int(grid) if grid else cu_count(dev)
+        # one flat fp32 buffer [all parameter gradients | loss]: the ONLY thing data parallel all-reduces
+        self.flat = torch.zeros(self.info.n_params + 1, dtype=torch.float32, device=dev)
+        self.flat_grad = self.flat[:self.info.n_params]
+        off = 0
+        for p in self.params:           # every p.grad is a view into the flat buffer
+            p.grad = self.flat_grad[off:off + p.numel()].view_as(p)
+            off += p.numel()
+        self.packed = torch.empty(self.info.packed_floats, dtype=torch.float32, device=dev)
+        self.partials = torch.empty(self.grid * self.info.partial_floats, dtype=torch.float32, device=dev)
+        self._loss_out = self.flat[self.info.n_params]
+        self._slate = None
+        self._calls = 0
+        self.seed_salt = 0             # per-rank salt of the dropout stream (data parallel)
+        self.kernel_events = None      # optional (start, end) torch.cuda.Event pair bracketing the pipeline kernel
+
+    def step(self, X, y, world_batch=None, keep1=None, keep2=None, seed=None, train=None):
+        """Run the fused pass on this rank's slates.  Returns the 0-dim LOCAL loss contribution, already
+        scaled for the global batch (sum over ranks == the reference's loss on the global batch)."""
+        info = self.info
+        require_device(X, y)
+        if X.dim() != 3 or X.shape[2] != info.F or tuple(y.shape[:2]) != tuple(X.shape[:2]):
+            raise ValueError(f"expected X [B,S,{info.F}] and y [B,S], got {tuple(X.shape)} / {tuple(y.shape)}")
+        B, S = int(X.shape[0]), int(X.shape[1])
+        if S not in (32, 64, 128):
+            raise ValueError(f"fused pass supports slate_length 32, 64 or 128 (got {S}); use net(x) + loss instead")
+        gb = int(world_batch) if world_batch else B
+        scale = 1.0 / gb if self.loss_kind == LOSS_APPROXNDCG else 1.0     # mean (approxNDCG.py:53) vs sum (listnet.py:16)
+        train = self.module.training if train is None else train
+        dropout = bool(train and self.module._ltr_dropout)
+        if seed is None:
+            seed = next_seed(self._calls) ^ ((self.seed_salt * 0xA24BAED4963EE407) & _MASK64)
+        self._calls += 1
+        with torch.cuda.device(self.device):
+            x2 = _docs(X, info)
+            yy = y.detach().reshape(B, S).to(torch.float32).contiguous()
+            k1, k2 = _mask(keep1, B * S, info.H1), _mask(keep2, B * S, info.H2)
+            if self._slate is None or self._slate.numel() < B:
+                self._slate = torch.empty(B, dtype=torch.float32, device=self.device)
+            pack_params(self.net, self.params, out=self.packed)
+            h = lib()
+            if self.kernel_events is not None:
+                self.kernel_events[0].record()
+            check(h.ltr_fused_step(self.net, self.loss_kind, _ptr(x2), _ptr(yy), B, S, _ptr(self.packed), int(dropout),
+                                   int(seed) & _MASK64, _ptr(k1), _ptr(k2), self.alpha, self.eps, self.pad,
+                                   int(self.apply_sigmoid), scale, _ptr(self._slate), _ptr(self.partials), self.grid,
+                                   _stream()), "ltr_fused_step")
+            if self.kernel_events is not None:
+                self.kernel_events[1].record()
+            check(h.ltr_mlp_reduce_grads(self.net, _ptr(self.partials), self.grid, _ptr(self.flat_grad), _stream()),
+                  "ltr_mlp_reduce_grads")
+            check(h.ltr_reduce_sum_f32(_ptr(self._slate), B, scale, self.flat.data_ptr() + 4 * self.info.n_params,
+                                       _stream()), "ltr_reduce_sum_f32")
+        return self._loss_out

@@ -1,0 +1,260 @@
+"""GPU parity tests for the slate pipeline (FC scorers + fused scorer/loss/backward launch) against the
+reference's golden vectors and the oracle.  Parity bar: max|delta|/max|ref| <= 1e-5 (fp32)."""
+import numpy as np
+import pytest
+import torch
+
+import ltr_oracle as O
+from conftest import golden, relerr
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-5
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    import ltr_mi355x
+    ltr_mi355x.lib()
+    return torch.device("cuda:0")
+
+
+def T(a, dev):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+
+def _load(net, g, case, dev):
+    net.load_state_dict({k: torch.from_numpy(g.arr(case, f"sd.{k}")) for k in case["keys"]})
+    return net.to(dev)
+
+
+def _grads(net):
+    return {k: p.grad.detach().cpu().numpy() for k, p in net.named_parameters()}
+
+
+def assert_grads(got, ref, tol=TOL):
+    """Per-tensor max-norm relative error; tensors whose true gradient is (numerically) zero -- the last
+    bias under a shift-invariant loss -- are compared on the scale of the largest gradient instead."""
+    top = max(float(np.abs(np.asarray(v)).max()) for v in ref.values())
+    for k, v in got.items():
+        r = np.asarray(ref[k], dtype=np.float64)
+        scale = max(float(np.abs(r).max()), 1e-4 * top, 1e-30)
+        err = float(np.abs(np.asarray(v, dtype=np.float64) - r).max()) / scale
+        assert err < tol, (k, err)
+
+
+# ------------------------------------------------------------------------------------- golden vectors
+def test_triple_golden(dev):
+    from architeture.tripleLayer import TripleLayerNet
+    from losses.approxNDCG import approxNDCGLoss
+    g = golden("scorers")
+    case = g.cases[0]
+    net = _load(TripleLayerNet(136), g, case, dev)
+    assert list(net.state_dict().keys()) == case["keys"]
+    x, y = T(g.arr(case, "x"), dev), T(g.arr(case, "y_true"), dev)
+    out = net(x, None, None)
+    assert out.shape == (3, 16, 1)
+    assert relerr(out.detach().cpu().numpy(), g.arr(case, "out")) < TOL
+    out.backward(T(g.arr(case, "gs"), dev))
+    assert_grads(_grads(net), {k: g.arr(case, f"gup.{k}") for k in case["keys"]})
+    net.zero_grad()
+    loss = approxNDCGLoss(net(x, None, None).squeeze(-1), y)
+    loss.backward()
+    assert relerr(loss.detach().cpu().numpy(), g.arr(case, "e2e_loss")) < TOL
+    assert_grads(_grads(net), {k: g.arr(case, f"ge2e.{k}") for k in case["keys"]})
+
+
+def test_double_golden(dev):
+    from architeture.doubleLayer import DoubleLayerNet
+    from losses.approxNDCG import approxNDCGLoss
+    g = golden("scorers")
+    case = g.cases[1]
+    net = _load(DoubleLayerNet(136), g, case, dev)
+    assert list(net.state_dict().keys()) == case["keys"]
+    x, y = T(g.arr(case, "x"), dev), T(g.arr(case, "y_true"), dev)
+    gs = T(g.arr(case, "gs"), dev)
+    pred = net.predict(x, None, None)
+    assert relerr(pred.detach().cpu().numpy(), g.arr(case, "out_eval")) < TOL
+    net.eval()
+    out = net(x, None, None)
+    assert torch.equal(out, pred)
+    out.backward(gs)
+    assert_grads(_grads(net), {k: g.arr(case, f"geval.{k}") for k in case["keys"]})
+    # training mode with the dropout masks the reference drew (explicit keep masks)
+    net.zero_grad()
+    net.train()
+    out = net(x, None, None, keep1=T(g.arr(case, "keep1"), dev), keep2=T(g.arr(case, "keep2"), dev))
+    assert relerr(out.detach().cpu().numpy(), g.arr(case, "out_train")) < TOL
+    out.backward(gs)
+    assert_grads(_grads(net), {k: g.arr(case, f"gtrain.{k}") for k in case["keys"]})
+    net.zero_grad()
+    net.eval()
+    loss = approxNDCGLoss(net(x, None, None).squeeze(-1), y)
+    loss.backward()
+    assert relerr(loss.detach().cpu().numpy(), g.arr(case, "e2e_loss")) < TOL
+    assert_grads(_grads(net), {k: g.arr(case, f"ge2e.{k}") for k in case["keys"]})
+
+
+# ------------------------------------------------------------------------------------- oracle, fresh inputs
+def _oracle_step(kind, sd, x, y, loss, k1=None, k2=None):
+    """fp64 CPU oracle: loss and parameter gradients by autograd over the restatement."""
+    p = {k: v.double().clone().requires_grad_(True) for k, v in sd.items()}
+    xd = x.double()
+    if kind == "triple":
+        s = O.triple_layer_forward(xd, p)
+    else:
+        s = O.double_layer_forward(xd, p, None if k1 is None else k1.double(), None if k2 is None else k2.double())
+    s = s.squeeze(-1)
+    l = O.approx_ndcg(s, y.double()) if loss == "approxNDCG" else O.listnet(y.double(), s)
+    l.backward()
+    return l.detach().numpy(), {k: v.grad.numpy() for k, v in p.items()}, s.detach().numpy()
+
+
+def _make(kind, dev, seed):
+    from architeture.doubleLayer import DoubleLayerNet
+    from architeture.tripleLayer import TripleLayerNet
+    torch.manual_seed(seed)
+    net = TripleLayerNet(136) if kind == "triple" else DoubleLayerNet(136)
+    sd = {k: v.detach().clone() for k, v in net.state_dict().items()}
+    return net.to(dev), sd
+
+
+@pytest.mark.parametrize("kind", ["triple", "double_eval", "double_train"])
+@pytest.mark.parametrize("S", [32, 64, 128])
+@pytest.mark.parametrize("B", [1, 5, 37])
+@pytest.mark.parametrize("loss", ["approxNDCG", "listnet"])
+def test_fused_step_vs_oracle(kind, S, B, loss, dev):
+    from ltr_mi355x.scorer import FusedRanker
+    net, sd = _make(kind.split("_")[0], dev, 7)
+    gen = torch.Generator().manual_seed(1000 + S + B)
+    x = torch.randn(B, S, 136, generator=gen)
+    y = torch.randint(0, 5, (B, S), generator=gen).float()
+    k1 = k2 = None
+    if kind == "double_train":
+        k1 = (torch.rand(B, S, 136, generator=gen) < 0.5).float()
+        k2 = (torch.rand(B, S, 136, generator=gen) < 0.5).float()
+        net.train()
+    else:
+        net.eval()
+    rl, rg, _ = _oracle_step(kind.split("_")[0], sd, x, y, loss, k1, k2)
+    ranker = FusedRanker(net, loss=loss)
+    out = ranker.step(x.to(dev), y.to(dev), keep1=None if k1 is None else k1.to(dev),
+                      keep2=None if k2 is None else k2.to(dev))
+    assert relerr(out.cpu().numpy(), rl) < TOL
+    assert_grads(_grads(net), rg)
+    # p.grad aliases the flat buffer, in parameters() order
+    flat = torch.cat([p.grad.reshape(-1) for p in net.parameters()])
+    assert torch.equal(flat, ranker.flat_grad)
+
+
+@pytest.mark.parametrize("kind", ["triple", "double"])
+@pytest.mark.parametrize("n_docs", [1, 100, 128, 1000, 128 * 300 + 17])
+def test_module_path_any_shape(kind, n_docs, dev):
+    """net(x) -> scores and backward under an arbitrary upstream gradient, any number of documents."""
+    net, sd = _make(kind, dev, 11)
+    net.eval()
+    gen = torch.Generator().manual_seed(n_docs)
+    x = torch.randn(n_docs, 136, generator=gen)
+    gs = torch.randn(n_docs, 1, generator=gen)
+    out = net(x.to(dev), None, None)
+    p = {k: v.double().clone().requires_grad_(True) for k, v in sd.items()}
+    ref = (O.triple_layer_forward if kind == "triple" else O.double_layer_forward)(x.double(), p)
+    assert out.shape == (n_docs, 1)
+    assert relerr(out.detach().cpu().numpy(), ref.detach().numpy()) < TOL
+    out.backward(gs.to(dev))
+    ref.backward(gs.double())
+    assert_grads(_grads(net), {k: v.grad.numpy() for k, v in p.items()})
+
+
+def test_dropout_stream(dev):
+    """The counter-based dropout stream: ~Bernoulli(0.5), layer/seed dependent, and the forward under it
+    equals the oracle forward under the exported masks; fused == unfused for the same seed."""
+    from ltr_mi355x import scorer
+    from losses.approxNDCG import approxNDCGLoss
+    net, sd = _make("double", dev, 3)
+    net.train()
+    B, S = 40, 64
+    gen = torch.Generator().manual_seed(9)
+    x = torch.randn(B, S, 136, generator=gen)
+    y = torch.randint(0, 5, (B, S), generator=gen).float()
+    seed = 0x1234567890ABCDEF
+    m1 = scorer.dropout_keep_mask(seed, 0, B * S, 136, dev)
+    m2 = scorer.dropout_keep_mask(seed, 1, B * S, 136, dev)
+    m1b = scorer.dropout_keep_mask(seed + 1, 0, B * S, 136, dev)
+    for m in (m1, m2, m1b):
+        assert abs(float(m.float().mean()) - 0.5) < 0.01
+    assert 0.45 < float((m1 == m2).float().mean()) < 0.55
+    assert 0.45 < float((m1 == m1b).float().mean()) < 0.55
+    scores = scorer.mlp_scores(net._ltr_net, net._ltr_params(), x.to(dev), dropout=True, seed=seed)
+    ref = O.double_layer_forward(x.double(), {k: v.double() for k, v in sd.items()},
+                                 m1.cpu().double().view(B, S, 136), m2.cpu().double().view(B, S, 136))
+    assert relerr(scores.detach().cpu().numpy(), ref.numpy()) < TOL
+    # unfused (forward launch, loss launch, backward launch) vs fused, same seed
+    loss = approxNDCGLoss(scores.squeeze(-1), y.to(dev))
+    loss.backward()
+    g_unfused = _grads(net)
+    ranker = scorer.FusedRanker(net, loss="approxNDCG")
+    lf = ranker.step(x.to(dev), y.to(dev), seed=seed)
+    assert relerr(lf.cpu().numpy(), loss.detach().cpu().numpy()) < 1e-6
+    assert_grads(_grads(net), g_unfused, 1e-6)
+
+
+def test_training_loop_matches_oracle(dev):
+    """The reference's minibatch loop (main_batch_execution.py:120-171) for a few Adam steps: same loss
+    trajectory as the oracle trained on the CPU from the same initial weights."""
+    from losses.approxNDCG import approxNDCGLoss
+    net, sd = _make("triple", dev, 2020)
+    gen = torch.Generator().manual_seed(2020)
+    Q, S, bs = 24, 32, 8
+    X = torch.randn(Q, S, 136, generator=gen)
+    Y = torch.randint(0, 5, (Q, S), generator=gen).float()
+    opt = torch.optim.Adam(net.parameters(), lr=1e-3)
+    p = {k: v.double().clone().requires_grad_(True) for k, v in sd.items()}
+    opt_ref = torch.optim.Adam(list(p.values()), lr=1e-3)
+    Xd, Yd = X.to(dev), Y.to(dev)
+    for it in range(Q // bs):
+        bx, by = Xd[it * bs:(it + 1) * bs], Yd[it * bs:(it + 1) * bs]
+        loss = approxNDCGLoss(torch.squeeze(net(bx, None, None)), by)
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        lref = O.approx_ndcg(O.triple_layer_forward(X[it * bs:(it + 1) * bs].double(), p).squeeze(-1),
+                             Y[it * bs:(it + 1) * bs].double())
+        opt_ref.zero_grad()
+        lref.backward()
+        opt_ref.step()
+        assert relerr(loss.detach().cpu().numpy(), lref.detach().numpy()) < 2e-5, it
+    for k, v in net.state_dict().items():
+        assert relerr(v.cpu().numpy(), p[k].detach().numpy()) < 1e-4, k
+
+
+def test_fused_full_size_properties(dev):
+    """BASELINE config 2: approxNDCG + DoubleLayerNet, 100k slates x 128 x 136 fp32 (6.96 GB resident).
+    Additivity over query shards (the data-parallel invariant), bit-reproducibility, loss range."""
+    from ltr_mi355x.scorer import FusedRanker
+    net, _ = _make("double", dev, 5)
+    net.eval()
+    B, S = 100_000, 128
+    gen = torch.Generator(device=dev).manual_seed(2020)
+    X = torch.randn(B, S, 136, device=dev, generator=gen)
+    y = torch.randint(0, 5, (B, S), device=dev, generator=gen).float()
+    ranker = FusedRanker(net, loss="approxNDCG")
+    l_all = ranker.step(X, y).clone()
+    g_all = ranker.flat_grad.clone()
+    l_again = ranker.step(X, y)
+    assert torch.equal(l_all, l_again) and torch.equal(g_all, ranker.flat_grad)
+    assert -1.0 <= float(l_all) <= 0.0 and bool(torch.isfinite(g_all).all())
+    h = 60_000
+    l0 = ranker.step(X[:h], y[:h], world_batch=B).clone()
+    g0 = ranker.flat_grad.clone()
+    l1 = ranker.step(X[h:], y[h:], world_batch=B).clone()
+    g1 = ranker.flat_grad.clone()
+    assert abs(float(l0 + l1) - float(l_all)) < 1e-5 * abs(float(l_all))
+    assert relerr((g0 + g1).cpu().numpy(), g_all.cpu().numpy()) < 1e-5
+    # a 256-slate prefix against the fp64 oracle
+    n = 256
+    sd = {k: v.detach().cpu() for k, v in net.state_dict().items()}
+    rl, rg, _ = _oracle_step("double", sd, X[:n].cpu(), y[:n].cpu(), "approxNDCG")
+    ln = ranker.step(X[:n], y[:n])
+    assert relerr(ln.cpu().numpy(), rl) < TOL
+    assert_grads(_grads(net), rg)
