@@ -7,8 +7,8 @@
 // and, in fused mode, the scorer->loss->backward chain of main_batch_execution.py:128-170.
 //
 // Layout of the computation (see DESIGN.md "slate pipeline"):
-//   * workgroup = 4 waves (one per SIMD, up to 512 VGPRs each); a SUPER-TILE is 128 consecutive documents
-//     (= 1 slate of 128, 2 of 64, 4 of 32); wave w owns documents 32w..32w+31 as two 16-document tiles.
+//   * workgroup = 8 waves (two per SIMD, 256 VGPRs each); a SUPER-TILE is 128 consecutive documents
+//     (= 1 slate of 128, 2 of 64, 4 of 32); wave w owns documents 16w..16w+15 as one 16-document tile.
 //   * every FC layer is computed TRANSPOSED with v_mfma_f32_16x16x4_f32 (exact fp32):
 //         z^T[n][doc] = sum_f W[n][f] x^T[f][doc]      A = W fragment, B = activations, lane&15 = document.
 //     The accumulator layout (row = 4*(lane>>4)+reg = output feature, col = lane&15 = document) is exactly
@@ -23,6 +23,7 @@
 //     (no float atomics: bit-reproducible gradients).
 #include "../../include/ltr_mi355x.h"
 #include "ltr_slate_losses.h"
+#include <stdlib.h>
 
 using namespace ltr;
 
@@ -31,14 +32,15 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 namespace {
 
 constexpr int kTileDocs = 128;   // documents per super-tile
-constexpr int kWaves = 4;
-constexpr int kThreads = 256;
-constexpr int kChunkDocs = 64;   // documents per dW staging chunk (one 16-doc tile of every wave)
+constexpr int kWaves = 8;        // 2 waves per SIMD: the co-resident wave hides LDS / L2 latency
+constexpr int kThreads = kWaves * 64;
+constexpr int kChunkDocs = 64;   // documents per dW staging chunk (the 16-doc tiles of 4 waves)
+constexpr int kRing = 6;         // weight fragments kept in flight per wave (1 KiB each, L2 -> registers)
 
 enum { ACT_ID = 0, ACT_RELU_DROP = 1, ACT_SIGMOID = 2 };
 enum { MODE_FWD = 0, MODE_BWD = 1, MODE_FUSED = 2 };
 
-template <int F_, int H1_, int H2_, int A1_, int A2_>
+template <int F_, int H1_, int H2_, int A1_, int A2_, int BH1_, int BH2_>
 struct NetT {
     static constexpr int F = F_, H1 = H1_, H2 = H2_, A1 = A1_, A2 = A2_;
     static constexpr int XT = (F + 1 + 15) / 16;    // x tiles incl. the ones feature at index F
@@ -50,6 +52,7 @@ struct NetT {
     static constexpr int NW2 = NT2 * H1T;           // dW2 tiles  [H2 rows][H1+1 cols]
     static constexpr int TW1 = (NW1 + kWaves - 1) / kWaves;
     static constexpr int TW2 = (NW2 + kWaves - 1) / kWaves;
+    static constexpr int BH1 = BH1_, BH2 = BH2_;    // row-band height of the per-wave dW tile sets
     // packed weights (floats)
     static constexpr int W1F_OFF = 0;                          // [NT1][XT][64][4]
     static constexpr int W2F_OFF = W1F_OFF + NT1 * XT * 256;   // [NT2][H1T][64][4]
@@ -65,9 +68,10 @@ struct NetT {
     static constexpr int NPARAM = H1 * F + H1 + H2 * H1 + H2 + H2 + 1;
     static_assert(LD % 32 == 16, "LDS stride must be 16 mod 32 for conflict-free fragment reads");
     static_assert(F % 4 == 0 && H1 % 4 == 0 && H2 % 4 == 0, "feature counts must be multiples of 4");
+    static_assert(NT1 % BH1 == 0 && NT2 % BH2 == 0, "band height must divide the dW row-tile count");
 };
-using DoubleNet = NetT<136, 136, 136, ACT_RELU_DROP, ACT_RELU_DROP>;   // doubleLayer.py:54-66
-using TripleNet = NetT<136, 64, 32, ACT_ID, ACT_SIGMOID>;              // tripleLayer.py:5-17
+using DoubleNet = NetT<136, 136, 136, ACT_RELU_DROP, ACT_RELU_DROP, 3, 3>;   // doubleLayer.py:54-66
+using TripleNet = NetT<136, 64, 32, ACT_ID, ACT_SIGMOID, 2, 2>;              // tripleLayer.py:5-17
 
 struct PipeArgs {
     const float *X;          // [n_docs][F]
@@ -87,6 +91,7 @@ struct PipeArgs {
     float alpha, eps, pad, gscale;
     int apply_sigmoid;
     int n_super;
+    int debug_skip;          // timing experiments only (env LTR_DEBUG_SKIP): 1 loss, 2 dW GEMMs, 4 dh1, 8 fc2, 16 fc1
 };
 
 __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
@@ -106,66 +111,106 @@ __device__ __forceinline__ unsigned keep_word(unsigned long long seed, int layer
     return mix32(h + 0x27D4EB2Fu * (unsigned)(word + 1));
 }
 
-// z^T tiles = W fragments x B fragments for BOTH 16-document tiles of the wave.
+// Sum over the 16 lanes of a DPP row (= the 16 documents sharing one q); the total lands in lane 15 of the row.
+__device__ __forceinline__ float row_sum_to_lane15(float v) {
+#define LTR_DPP_SHR(x, n) __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x110 + (n), 0xF, 0xF, false))
+    v += LTR_DPP_SHR(v, 1);
+    v += LTR_DPP_SHR(v, 2);
+    v += LTR_DPP_SHR(v, 4);
+    v += LTR_DPP_SHR(v, 8);
+#undef LTR_DPP_SHR
+    return v;
+}
+
+// z^T tiles = W fragments x B fragments for the wave's 16-document tile.
 // wf: [NT][KT][64] float4, lane-ordered; lane (q = lane>>4, i = lane&15) holds W[16*To + i][16*T + 4q + s], s = 0..3.
+// Output tiles are processed in pairs (two independent accumulator chains); the fragments stream through a
+// ring of kRing registers-quads loaded kRing steps ahead of their use, so L2 latency hides behind MFMAs.
+// Fragments are fetched with buffer loads: ONE descriptor (SGPRs) + ONE lane-offset VGPR + a scalar byte offset
+// per fragment.  (With plain pointers hipcc hoists all NT*KT 64-bit fragment addresses out of the persistent
+// loop and spills them.)
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ f32x4 load_frag(__amdgpu_buffer_rsrc_t rsrc, int lane_off, int byte_off) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, lane_off, byte_off, 0));
+}
+
 template <int NT, int KT, int KMAX, int NMAX>
-__device__ __forceinline__ void gemm_wx(const f32x4 *__restrict__ wf, int lane, const f32x4 (&bin)[2][KMAX],
-                                        f32x4 (&out)[2][NMAX]) {
-#pragma unroll
-    for (int To = 0; To < NT; ++To) {
-        f32x4 c0 = {0.f, 0.f, 0.f, 0.f}, c1 = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int T = 0; T < KT; ++T) {
-            const f32x4 a = wf[(To * KT + T) * 64 + lane];
-#pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                c0 = mfma4(a[s], bin[0][T][s], c0);
-                c1 = mfma4(a[s], bin[1][T][s], c1);
-            }
+__device__ __forceinline__ void gemm_wx(__amdgpu_buffer_rsrc_t rsrc, int base_bytes, int lane_off,
+                                        const f32x4 (&bin)[KMAX], f32x4 (&out)[NMAX]) {
+    constexpr int NSTEP = NT * KT;
+    // step n -> (To, T): pairs of output tiles interleaved so consecutive steps alternate accumulators
+    auto tile_of = [](int n, int &To, int &T) {
+        constexpr int NPAIR = NT / 2;
+        if (n < NPAIR * 2 * KT) {
+            const int pr = n / (2 * KT), r = n - pr * 2 * KT;
+            To = 2 * pr + (r & 1);
+            T = r >> 1;
+        } else {
+            To = NT - 1;
+            T = n - NPAIR * 2 * KT;
         }
-        out[0][To] = c0;
-        out[1][To] = c1;
-        // one scheduling region per output tile: stops hipcc hoisting all NT*KT fragment loads to the top
-        // of the (fully unrolled) GEMM, which costs > 300 VGPRs and spills
+    };
+    f32x4 ring[kRing];
+#pragma unroll
+    for (int n = 0; n < kRing; ++n) {
+        if (n < NSTEP) {
+            int To, T;
+            tile_of(n, To, T);
+            ring[n] = load_frag(rsrc, lane_off, base_bytes + (To * KT + T) * 1024);
+        }
+    }
+#pragma unroll
+    for (int To = 0; To < NT; ++To) out[To] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int n = 0; n < NSTEP; ++n) {
+        int To, T;
+        tile_of(n, To, T);
+        const f32x4 a = ring[n % kRing];
+        if (n + kRing < NSTEP) {
+            int To2, T2;
+            tile_of(n + kRing, To2, T2);
+            ring[n % kRing] = load_frag(rsrc, lane_off, base_bytes + (To2 * KT + T2) * 1024);
+        }
+#pragma unroll
+        for (int s = 0; s < 4; ++s) out[To] = mfma4(a[s], bin[T][s], out[To]);
+        // pin [prefetch n+kRing][4 MFMAs of n] as one scheduling region: left alone, hipcc hoists every
+        // fragment load of the unrolled GEMM to its top (SSA renaming defeats the ring) and spills
         __builtin_amdgcn_sched_barrier(0);
     }
 }
 
-// Activation (+ dropout) on accumulator tiles; features >= H forced to 0, then the ones feature at index H.
+// Activation (+ dropout) on accumulator tiles; features >= H forced to 0.
 template <int ACT, int H, int NT, int NMAX>
-__device__ __forceinline__ void activate(f32x4 (&h)[2][NMAX], int q, const PipeArgs &a, int layer,
-                                         const uint8_t *keep, long long doc0, long long doc1) {
+__device__ __forceinline__ void activate(f32x4 (&h)[NMAX], int q, const PipeArgs &a, int layer, const uint8_t *keep,
+                                         long long doc) {
+    const bool in_range = doc < a.n_docs;
 #pragma unroll
-    for (int t = 0; t < 2; ++t) {
-        const long long doc = t == 0 ? doc0 : doc1;
-        const bool in_range = doc < a.n_docs;
-#pragma unroll
-        for (int To = 0; To < NT; ++To) {
-            unsigned kb = 0xFu;
-            if (ACT == ACT_RELU_DROP && a.dropout) {
-                if (keep) {
-                    const int n0 = 16 * To + 4 * q;
-                    unsigned bytes = 0;
-                    if (in_range && n0 < H) bytes = *reinterpret_cast<const unsigned *>(keep + doc * H + n0);
-                    kb = ((bytes & 0xFFu) ? 1u : 0u) | ((bytes & 0xFF00u) ? 2u : 0u) | ((bytes & 0xFF0000u) ? 4u : 0u) |
-                         ((bytes & 0xFF000000u) ? 8u : 0u);
-                } else {
-                    const unsigned wbits = keep_word(a.seed, layer, doc, To >> 1);
-                    kb = (wbits >> (16 * (To & 1) + 4 * q)) & 0xFu;
-                }
+    for (int To = 0; To < NT; ++To) {
+        unsigned kb = 0xFu;
+        if (ACT == ACT_RELU_DROP && a.dropout) {
+            if (keep) {
+                const int n0 = 16 * To + 4 * q;
+                unsigned bytes = 0;
+                if (in_range && n0 < H) bytes = *reinterpret_cast<const unsigned *>(keep + doc * H + n0);
+                kb = ((bytes & 0xFFu) ? 1u : 0u) | ((bytes & 0xFF00u) ? 2u : 0u) | ((bytes & 0xFF0000u) ? 4u : 0u) |
+                     ((bytes & 0xFF000000u) ? 8u : 0u);
+            } else {
+                const unsigned wbits = keep_word(a.seed, layer, doc, To >> 1);
+                kb = (wbits >> (16 * (To & 1) + 4 * q)) & 0xFu;
             }
+        }
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int n = 16 * To + 4 * q + r;
-                float v = h[t][To][r];
-                if (ACT == ACT_RELU_DROP) {
-                    v = fmaxf(v, 0.f);
-                    if (a.dropout) v = ((kb >> r) & 1u) ? 2.f * v : 0.f;
-                } else if (ACT == ACT_SIGMOID) {
-                    v = 1.f / (1.f + __expf(-v));
-                }
-                h[t][To][r] = (n < H) ? v : 0.f;
+        for (int r = 0; r < 4; ++r) {
+            const int n = 16 * To + 4 * q + r;
+            float v = h[To][r];
+            if (ACT == ACT_RELU_DROP) {
+                v = fmaxf(v, 0.f);
+                if (a.dropout) v = ((kb >> r) & 1u) ? 2.f * v : 0.f;
+            } else if (ACT == ACT_SIGMOID) {
+                v = 1.f / (1.f + __expf(-v));
             }
+            h[To][r] = (n < H) ? v : 0.f;
         }
     }
 }
@@ -177,29 +222,95 @@ __device__ __forceinline__ float act_grad(float h, int dropout) {
     return 1.f;
 }
 
-// dW tiles of this wave += A^T B over one 64-document chunk.
-//   As: LDS [64][LD]   rows = chunk documents, A fragment = As[4s+q][16*To + (lane&15)]
-//   Bs: LDS base of the B rows; row of chunk document c is Bs[brow(c)*LD ...]
-template <int TW, int NTI, int NTOT, int LD, class BRow>
-__device__ __forceinline__ void dw_chunk(f32x4 (&acc)[TW], const float *As, const float *Bs, int w, int lane, BRow brow) {
-    const int q = lane >> 4, i = lane & 15;
+// Per-wave dW tile sets, fixed at compile time.  The NR x NC tile grid is walked in row bands of height BH,
+// column-major inside a band; wave W owns the contiguous run [W*TW, W*TW+TW) of that walk: a compact ~BH x TW/BH
+// block whose A (row) and B (column) fragments are shared between its tiles.
+template <int NR, int NC, int BH>
+__host__ __device__ constexpr int dw_row(int g) { return (g / (NC * BH)) * BH + (g % (NC * BH)) % BH; }
+template <int NR, int NC, int BH>
+__host__ __device__ constexpr int dw_col(int g) { return (g % (NC * BH)) / BH; }
+
+// dW tiles of wave W += A^T B over one 64-document chunk.
+//   a_base / b_base: this lane's LDS addresses of A[row q][16*0 + i] / B[row q][16*0 + i] for k-step 0;
+//   k-step s adds 4*LD floats; tile (To, Ti) adds 16*To / 16*Ti floats: all immediates.
+template <int W, int TW, int NR, int NC, int BH, int LD>
+__device__ __forceinline__ void dw_chunk_w(f32x4 (&acc)[TW], const float *a_base, const float *b_base) {
+    constexpr int NTOT = NR * NC;
 #pragma unroll 2
     for (int s = 0; s < kChunkDocs / 4; ++s) {
-        const float *arow = As + (4 * s + q) * LD + i;
-        const float *brw = Bs + brow(4 * s + q) * LD + i;
+        const float *ar = a_base + s * 4 * LD;
+        const float *br = b_base + s * 4 * LD;
+        float af[NR], bf[NC];
 #pragma unroll
-        for (int n = 0; n < TW; ++n) {
-            const int idx = w + kWaves * n;
-            if (idx < NTOT) {   // wave-uniform
-                const int To = idx / NTI, Ti = idx - To * NTI;
-                acc[n] = mfma4(arow[16 * To], brw[16 * Ti], acc[n]);
+        for (int j = 0; j < TW; ++j) {
+            constexpr int dummy = 0;
+            (void)dummy;
+            const int g = W * TW + j;
+            if (g < NTOT) {
+                const int To = dw_row<NR, NC, BH>(g), Ti = dw_col<NR, NC, BH>(g);
+                bool first_a = true, first_b = true;
+#pragma unroll
+                for (int jj = 0; jj < j; ++jj) {
+                    const int g2 = W * TW + jj;
+                    if (dw_row<NR, NC, BH>(g2) == To) first_a = false;
+                    if (dw_col<NR, NC, BH>(g2) == Ti) first_b = false;
+                }
+                if (first_a) af[To] = ar[16 * To];
+                if (first_b) bf[Ti] = br[16 * Ti];
             }
+        }
+#pragma unroll
+        for (int j = 0; j < TW; ++j) {
+            const int g = W * TW + j;
+            if (g < NTOT) acc[j] = mfma4(af[dw_row<NR, NC, BH>(g)], bf[dw_col<NR, NC, BH>(g)], acc[j]);
         }
     }
 }
 
+template <int TW, int NR, int NC, int BH, int LD>
+__device__ __forceinline__ void dw_chunk(int w, f32x4 (&acc)[TW], const float *a_base, const float *b_base) {
+    switch (w) {   // wave-uniform: one specialised, branch-free body per wave
+        case 0: dw_chunk_w<0, TW, NR, NC, BH, LD>(acc, a_base, b_base); break;
+        case 1: dw_chunk_w<1, TW, NR, NC, BH, LD>(acc, a_base, b_base); break;
+        case 2: dw_chunk_w<2, TW, NR, NC, BH, LD>(acc, a_base, b_base); break;
+        case 3: dw_chunk_w<3, TW, NR, NC, BH, LD>(acc, a_base, b_base); break;
+        case 4: dw_chunk_w<4, TW, NR, NC, BH, LD>(acc, a_base, b_base); break;
+        case 5: dw_chunk_w<5, TW, NR, NC, BH, LD>(acc, a_base, b_base); break;
+        case 6: dw_chunk_w<6, TW, NR, NC, BH, LD>(acc, a_base, b_base); break;
+        default: dw_chunk_w<7, TW, NR, NC, BH, LD>(acc, a_base, b_base); break;
+    }
+}
+
+// accumulator tiles of wave W -> workgroup partial (row = 4q + r, col = lane & 15)
+template <int W, int TW, int NR, int NC, int BH>
+__device__ __forceinline__ void dw_store_w(const f32x4 (&acc)[TW], float *dst, int q, int d) {
+#pragma unroll
+    for (int j = 0; j < TW; ++j) {
+        const int g = W * TW + j;
+        if (g < NR * NC) {
+            const int To = dw_row<NR, NC, BH>(g), Ti = dw_col<NR, NC, BH>(g);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) dst[(16 * To + 4 * q + r) * (NC * 16) + 16 * Ti + d] = acc[j][r];
+        }
+    }
+}
+
+template <int TW, int NR, int NC, int BH>
+__device__ __forceinline__ void dw_store(int w, const f32x4 (&acc)[TW], float *dst, int q, int d) {
+    switch (w) {
+        case 0: dw_store_w<0, TW, NR, NC, BH>(acc, dst, q, d); break;
+        case 1: dw_store_w<1, TW, NR, NC, BH>(acc, dst, q, d); break;
+        case 2: dw_store_w<2, TW, NR, NC, BH>(acc, dst, q, d); break;
+        case 3: dw_store_w<3, TW, NR, NC, BH>(acc, dst, q, d); break;
+        case 4: dw_store_w<4, TW, NR, NC, BH>(acc, dst, q, d); break;
+        case 5: dw_store_w<5, TW, NR, NC, BH>(acc, dst, q, d); break;
+        case 6: dw_store_w<6, TW, NR, NC, BH>(acc, dst, q, d); break;
+        default: dw_store_w<7, TW, NR, NC, BH>(acc, dst, q, d); break;
+    }
+}
+
 template <class N, int MODE>
-__global__ void __launch_bounds__(kThreads, 1) slate_pipeline_kernel(const PipeArgs a) {
+__global__ void __launch_bounds__(kThreads, 2) slate_pipeline_kernel(const PipeArgs a) {
     constexpr int LD = N::LD;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float *Xs = smem;                         // [128][LD]
@@ -211,17 +322,18 @@ __global__ void __launch_bounds__(kThreads, 1) slate_pipeline_kernel(const PipeA
     float *gg = gn + kTileDocs;               // [128] loss scratch
     float *dsc = gg + kTileDocs;              // [128] d loss / d score
     float *w3s = dsc + kTileDocs;             // [NT2*16 + 16] w3 (zero padded), b3
-    float *dw3 = w3s + N::NT2 * 16 + 16;      // [4][NT2*16] per-wave dw3 accumulators
-    float *scratch = dw3 + kWaves * N::NT2 * 16;   // [256 + 128] slate-group scratch
+    float *dw3 = w3s + N::NT2 * 16 + 16;      // [kWaves][NT2*16] per-wave dw3 accumulators
+    float *scratch = dw3 + kWaves * N::NT2 * 16;   // [512 + 4*32] slate-group scratch
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int q = lane >> 4, d = lane & 15;
 
-    const f32x4 *W1F = reinterpret_cast<const f32x4 *>(a.packed + N::W1F_OFF);
-    const f32x4 *W2F = reinterpret_cast<const f32x4 *>(a.packed + N::W2F_OFF);
-    const f32x4 *W2T = reinterpret_cast<const f32x4 *>(a.packed + N::W2T_OFF);
+    // packed weights behind one buffer descriptor (wave-uniform: kernel argument)
+    const __amdgpu_buffer_rsrc_t wrsrc =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.packed), 0, N::PACKED * 4, 0x00020000);
+    const int lane_off = lane * 16;
 
     for (int j = tid; j < N::NT2 * 16 + 16; j += kThreads) w3s[j] = a.packed[N::W3_OFF + j];
     for (int j = tid; j < kWaves * N::NT2 * 16; j += kThreads) dw3[j] = 0.f;
@@ -233,15 +345,18 @@ __global__ void __launch_bounds__(kThreads, 1) slate_pipeline_kernel(const PipeA
 #pragma unroll
         for (int n = 0; n < N::TW2; ++n) accW2[n] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
+    const int my_row = 16 * w + d;                         // this lane's document inside the super-tile
+    const int chunk = w >> 2;                              // dW chunk this wave's tile belongs to
+    const int crow = 16 * (w & 3) + d;                     // ... and its row inside the chunk
 
     for (int st = blockIdx.x; st < a.n_super; st += gridDim.x) {
         const long long doc_base = (long long)st * kTileDocs;
         __syncthreads();   // previous super-tile done with Xs / sc / dsc
-        // ---- X: HBM -> LDS, coalesced 16 B per lane; the wave's 32 documents are contiguous in memory.
+        // ---- X: HBM -> LDS, coalesced 16 B per lane; the wave's 16 documents are contiguous in memory.
         {
             constexpr int V4_PER_ROW = N::F / 4;
-            constexpr int V4 = 32 * V4_PER_ROW;             // float4s per wave
-            const long long row0 = doc_base + 32 * w;
+            constexpr int V4 = 16 * V4_PER_ROW;             // float4s per wave
+            const long long row0 = doc_base + 16 * w;
             const f32x4 *src = reinterpret_cast<const f32x4 *>(a.X + row0 * N::F);
 #pragma unroll
             for (int m = 0; m < (V4 + 63) / 64; ++m) {
@@ -250,15 +365,16 @@ __global__ void __launch_bounds__(kThreads, 1) slate_pipeline_kernel(const PipeA
                     const int r = e / V4_PER_ROW, c4 = e - r * V4_PER_ROW;
                     f32x4 v = {0.f, 0.f, 0.f, 0.f};
                     if (row0 + r < a.n_docs) v = src[e];
-                    *reinterpret_cast<f32x4 *>(Xs + (32 * w + r) * LD + 4 * c4) = v;
+                    *reinterpret_cast<f32x4 *>(Xs + (16 * w + r) * LD + 4 * c4) = v;
                 }
             }
             // ones feature at column F, zeros up to LD
-            for (int e = lane; e < 32 * ((LD - N::F) / 4); e += 64) {
-                const int r = e / ((LD - N::F) / 4), c4 = e - r * ((LD - N::F) / 4);
+            constexpr int PADV4 = (LD - N::F) / 4;
+            for (int e = lane; e < 16 * PADV4; e += 64) {
+                const int r = e / PADV4, c4 = e - r * PADV4;
                 f32x4 v = {0.f, 0.f, 0.f, 0.f};
                 if (c4 == 0) v[0] = 1.f;
-                *reinterpret_cast<f32x4 *>(Xs + (32 * w + r) * LD + N::F + 4 * c4) = v;
+                *reinterpret_cast<f32x4 *>(Xs + (16 * w + r) * LD + N::F + 4 * c4) = v;
             }
         }
         if (MODE == MODE_FUSED && tid < kTileDocs) {
@@ -273,51 +389,44 @@ __global__ void __launch_bounds__(kThreads, 1) slate_pipeline_kernel(const PipeA
         }
         __syncthreads();
 
-        const long long gdoc0 = doc_base + 32 * w + d, gdoc1 = gdoc0 + 16;
+        const long long gdoc = doc_base + my_row;
         // ---- fc1
-        f32x4 h1[2][N::H1T];
+        f32x4 h1[N::H1T];
         {
-            f32x4 xb[2][N::XT];
+            f32x4 xb[N::XT];
 #pragma unroll
-            for (int t = 0; t < 2; ++t)
+            for (int T = 0; T < N::XT; ++T)
+                xb[T] = *reinterpret_cast<const f32x4 *>(Xs + my_row * LD + 16 * T + 4 * q);
+            if (N::H1T > N::NT1) h1[N::H1T - 1] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (!(a.debug_skip & 16)) gemm_wx<N::NT1, N::XT>(wrsrc, N::W1F_OFF * 4, lane_off, xb, h1);
+            else
 #pragma unroll
-                for (int T = 0; T < N::XT; ++T)
-                    xb[t][T] = *reinterpret_cast<const f32x4 *>(Xs + (32 * w + 16 * t + d) * LD + 16 * T + 4 * q);
-            gemm_wx<N::NT1, N::XT>(W1F, lane, xb, h1);
+                for (int To = 0; To < N::NT1; ++To) h1[To] = xb[To];
         }
-        if (N::H1T > N::NT1) {
-#pragma unroll
-            for (int t = 0; t < 2; ++t) h1[t][N::H1T - 1] = f32x4{0.f, 0.f, 0.f, 0.f};
-        }
-        activate<N::A1, N::H1, N::NT1>(h1, q, a, 0, a.keep1, gdoc0, gdoc1);
+        activate<N::A1, N::H1, N::NT1>(h1, q, a, 0, a.keep1, gdoc);
         {   // ones feature at index H1 (carries b2 through fc2 and db2 through dW2)
             constexpr int Tn = N::H1 / 16, p = N::H1 % 16;
-#pragma unroll
-            for (int t = 0; t < 2; ++t) h1[t][Tn][p % 4] = (q == p / 4) ? 1.f : h1[t][Tn][p % 4];
+            h1[Tn][p % 4] = (q == p / 4) ? 1.f : h1[Tn][p % 4];
         }
         // ---- fc2
-        f32x4 h2[2][N::NT2];
-        gemm_wx<N::NT2, N::H1T>(W2F, lane, h1, h2);
-        activate<N::A2, N::H2, N::NT2>(h2, q, a, 1, a.keep2, gdoc0, gdoc1);
+        f32x4 h2[N::NT2];
+        if (!(a.debug_skip & 8)) gemm_wx<N::NT2, N::H1T>(wrsrc, N::W2F_OFF * 4, lane_off, h1, h2);
+        else
+#pragma unroll
+            for (int To = 0; To < N::NT2; ++To) h2[To] = h1[To];
+        activate<N::A2, N::H2, N::NT2>(h2, q, a, 1, a.keep2, gdoc);
         // ---- fc3: s = w3 . h2 + b3, reduced over the 4 q-lanes of each document
         {
-            float p0 = 0.f, p1 = 0.f;
+            float p0 = 0.f;
 #pragma unroll
             for (int To = 0; To < N::NT2; ++To) {
                 const f32x4 wv = *reinterpret_cast<const f32x4 *>(w3s + 16 * To + 4 * q);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    p0 += wv[r] * h2[0][To][r];
-                    p1 += wv[r] * h2[1][To][r];
-                }
+                for (int r = 0; r < 4; ++r) p0 += wv[r] * h2[To][r];
             }
-            p0 += __shfl_xor(p0, 16, 64); p0 += __shfl_xor(p0, 32, 64);
-            p1 += __shfl_xor(p1, 16, 64); p1 += __shfl_xor(p1, 32, 64);
-            const float b3 = w3s[N::NT2 * 16];
-            if (q == 0) {
-                sc[32 * w + d] = p0 + b3;
-                sc[32 * w + 16 + d] = p1 + b3;
-            }
+            p0 += __shfl_xor(p0, 16, 64);
+            p0 += __shfl_xor(p0, 32, 64);
+            if (q == 0) sc[my_row] = p0 + w3s[N::NT2 * 16];
         }
         if (MODE == MODE_FWD) {
             __syncthreads();
@@ -325,9 +434,12 @@ __global__ void __launch_bounds__(kThreads, 1) slate_pipeline_kernel(const PipeA
             continue;
         }
         // ---- listwise loss on the LDS-resident scores (fused) -> dsc
-        if (MODE == MODE_FUSED) {
+        if (MODE == MODE_FUSED && (a.debug_skip & 1)) {
             __syncthreads();
-            const int group = 2 * a.S;                 // S in {32, 64, 128}: 2 threads per document row
+            if (tid < kTileDocs) dsc[tid] = 1e-3f * sc[tid];
+        } else if (MODE == MODE_FUSED) {
+            __syncthreads();
+            const int group = 4 * a.S;                 // S in {32, 64, 128}: 4 threads per document row
             const int gid = tid / group;
             const SlateGroup g = make_group(a.S, group, scratch + gid * (group + 32));
             const int so = gid * a.S;
@@ -345,99 +457,83 @@ __global__ void __launch_bounds__(kThreads, 1) slate_pipeline_kernel(const PipeA
 
         // ---- backward through fc3: dw3 += ds * h2 (sum over documents = lanes d), dz2 = ds * w3 * act2'(h2)
         // documents past the end of the batch must not contribute to any gradient
-        const float ds0 = gdoc0 < a.n_docs ? dsc[32 * w + d] : 0.f;
-        const float ds1 = gdoc1 < a.n_docs ? dsc[32 * w + 16 + d] : 0.f;
-        {
-            float sb = (q == 0) ? ds0 + ds1 : 0.f;
-            db3 += wave_allsum(sb);
-        }
+        const float ds0 = gdoc < a.n_docs ? dsc[my_row] : 0.f;
+        db3 += wave_allsum((q == 0) ? ds0 : 0.f);
 #pragma unroll
         for (int To = 0; To < N::NT2; ++To) {
             const f32x4 wv = *reinterpret_cast<const f32x4 *>(w3s + 16 * To + 4 * q);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                float v = ds0 * h2[0][To][r] + ds1 * h2[1][To][r];
-                v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64);
-                v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64);
-                if (d == 0) dw3[w * N::NT2 * 16 + 16 * To + 4 * q + r] += v;
-                h2[0][To][r] = ds0 * wv[r] * act_grad<N::A2>(h2[0][To][r], a.dropout);
-                h2[1][To][r] = ds1 * wv[r] * act_grad<N::A2>(h2[1][To][r], a.dropout);
+                const float v = row_sum_to_lane15(ds0 * h2[To][r]);
+                if (d == 15) dw3[w * N::NT2 * 16 + 16 * To + 4 * q + r] += v;
+                h2[To][r] = ds0 * wv[r] * act_grad<N::A2>(h2[To][r], a.dropout);
             }
         }
         // h2 now holds dz2.
-        // ---- dh1^T = W2^T dz2^T  (A = packed W2^T fragments, B = dz2 registers)
-        f32x4 dz1[2][N::NT1];
-        gemm_wx<N::NT1, N::NT2>(W2T, lane, h2, dz1);
-
-        // ---- dW2 += dz2^T [h1 | 1] over the two 64-document chunks
+        // ---- dW2 += dz2^T [h1 | 1] over the two 64-document chunks (tiles of waves 0-3, then waves 4-7)
 #pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            if (t > 0) __syncthreads();   // chunk 0 fully consumed
+        for (int c = 0; c < 2; ++c) {
+            if (c > 0) __syncthreads();   // chunk 0 fully consumed
+            if (chunk == c) {
 #pragma unroll
-            for (int To = 0; To < N::NT2; ++To)
-                *reinterpret_cast<f32x4 *>(Ds + (16 * w + d) * LD + 16 * To + 4 * q) = h2[t][To];
+                for (int To = 0; To < N::NT2; ++To)
+                    *reinterpret_cast<f32x4 *>(Ds + crow * LD + 16 * To + 4 * q) = h2[To];
 #pragma unroll
-            for (int T = 0; T < N::H1T; ++T)
-                *reinterpret_cast<f32x4 *>(Hs + (16 * w + d) * LD + 16 * T + 4 * q) = h1[t][T];
+                for (int T = 0; T < N::H1T; ++T)
+                    *reinterpret_cast<f32x4 *>(Hs + crow * LD + 16 * T + 4 * q) = h1[T];
+            }
             __syncthreads();
-            dw_chunk<N::TW2, N::H1T, N::NW2, LD>(accW2, Ds, Hs, w, lane, [](int c) { return c; });
+            if (!(a.debug_skip & 2))
+                dw_chunk<N::TW2, N::NT2, N::H1T, N::BH2, LD>(w, accW2, Ds + q * LD + d, Hs + q * LD + d);
         }
-        // ---- dz1 = dh1 * act1'(h1), features >= H1 (incl. the ones feature) zeroed
+        // ---- dh1^T = W2^T dz2^T  (A = packed W2^T fragments, B = dz2 registers), then
+        //      dz1 = dh1 * act1'(h1), features >= H1 (incl. the ones feature) zeroed
+        f32x4 dz1[N::NT1];
+        if (!(a.debug_skip & 4)) gemm_wx<N::NT1, N::NT2>(wrsrc, N::W2T_OFF * 4, lane_off, h2, dz1);
+        else
 #pragma unroll
-        for (int t = 0; t < 2; ++t)
+            for (int To = 0; To < N::NT1; ++To) dz1[To] = h2[To < N::NT2 ? To : 0];
 #pragma unroll
-            for (int To = 0; To < N::NT1; ++To)
+        for (int To = 0; To < N::NT1; ++To)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int n = 16 * To + 4 * q + r;
-                    dz1[t][To][r] = (n < N::H1) ? dz1[t][To][r] * act_grad<N::A1>(h1[t][To][r], a.dropout) : 0.f;
-                }
+            for (int r = 0; r < 4; ++r) {
+                const int n = 16 * To + 4 * q + r;
+                dz1[To][r] = (n < N::H1) ? dz1[To][r] * act_grad<N::A1>(h1[To][r], a.dropout) : 0.f;
+            }
         // ---- dW1 += dz1^T [x | 1]; B operand straight from the X tile in LDS
 #pragma unroll
-        for (int t = 0; t < 2; ++t) {
+        for (int c = 0; c < 2; ++c) {
             __syncthreads();              // previous chunk's readers are done with Ds
+            if (chunk == c) {
 #pragma unroll
-            for (int To = 0; To < N::NT1; ++To)
-                *reinterpret_cast<f32x4 *>(Ds + (16 * w + d) * LD + 16 * To + 4 * q) = dz1[t][To];
+                for (int To = 0; To < N::NT1; ++To)
+                    *reinterpret_cast<f32x4 *>(Ds + crow * LD + 16 * To + 4 * q) = dz1[To];
+            }
             __syncthreads();
-            dw_chunk<N::TW1, N::XT, N::NW1, LD>(accW1, Ds, Xs, w, lane,
-                                               [t](int c) { return 32 * (c >> 4) + 16 * t + (c & 15); });
+            if (!(a.debug_skip & 2))
+                dw_chunk<N::TW1, N::NT1, N::XT, N::BH1, LD>(w, accW1, Ds + q * LD + d, Xs + (64 * c + q) * LD + d);
         }
     }
 
     if (MODE == MODE_FWD) return;
-    // ---- per-workgroup partial gradients -> workspace (accumulator layout: row = 4q + r, col = lane & 15)
+    // ---- per-workgroup partial gradients -> workspace
     float *part = a.partials + (size_t)blockIdx.x * N::PART;
-#pragma unroll
-    for (int n = 0; n < N::TW1; ++n) {
-        const int idx = w + kWaves * n;
-        if (idx < N::NW1) {
-            const int To = idx / N::XT, Ti = idx - To * N::XT;
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-                part[N::P_W1 + (16 * To + 4 * q + r) * (N::XT * 16) + 16 * Ti + d] = accW1[n][r];
-        }
-    }
-#pragma unroll
-    for (int n = 0; n < N::TW2; ++n) {
-        const int idx = w + kWaves * n;
-        if (idx < N::NW2) {
-            const int To = idx / N::H1T, Ti = idx - To * N::H1T;
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-                part[N::P_W2 + (16 * To + 4 * q + r) * (N::H1T * 16) + 16 * Ti + d] = accW2[n][r];
-        }
-    }
+    dw_store<N::TW1, N::NT1, N::XT, N::BH1>(w, accW1, part + N::P_W1, q, d);
+    dw_store<N::TW2, N::NT2, N::H1T, N::BH2>(w, accW2, part + N::P_W2, q, d);
     __syncthreads();
     for (int j = tid; j < N::NT2 * 16; j += kThreads) {
         float s = 0.f;
         for (int ww = 0; ww < kWaves; ++ww) s += dw3[ww * N::NT2 * 16 + j];
         part[N::P_W3 + j] = s;
     }
-    // db3: every lane of a wave holds the wave's sum; combine the 4 waves through LDS in fixed order
+    // db3: every lane of a wave holds the wave's sum; combine the waves through LDS in fixed order
     if (lane == 0) scratch[w] = db3;
     __syncthreads();
-    if (tid == 0) part[N::P_B3] = scratch[0] + scratch[1] + scratch[2] + scratch[3];
+    if (tid == 0) {
+        float s = 0.f;
+        for (int ww = 0; ww < kWaves; ++ww) s += scratch[ww];
+        part[N::P_B3] = s;
+    }
 }
 
 // The keep mask the pipeline's counter-based dropout stream produces (tests / reproducibility tooling).
@@ -506,7 +602,7 @@ __global__ void reduce_grads_kernel(const float *__restrict__ partials, int npar
 template <class N>
 constexpr size_t pipeline_lds() {
     return sizeof(float) * (size_t)(kTileDocs * N::LD + 2 * kChunkDocs * N::LD + 5 * kTileDocs + N::NT2 * 16 + 16 +
-                                    kWaves * N::NT2 * 16 + 4 * (128 + 32) + 64);
+                                    kWaves * N::NT2 * 16 + kThreads + 4 * 32 + 64);
 }
 
 inline int status() {
@@ -597,6 +693,8 @@ static int fill_common(PipeArgs &a, int net, const float *X, int64_t n_docs, con
     a.keep1 = keep1;
     a.keep2 = keep2;
     a.n_super = (int)((n_docs + kTileDocs - 1) / kTileDocs);
+    static const int dbg = getenv("LTR_DEBUG_SKIP") ? atoi(getenv("LTR_DEBUG_SKIP")) : 0;
+    a.debug_skip = dbg;
     return LTR_OK;
 }
 

@@ -32,15 +32,22 @@ def _grads(net):
     return {k: p.grad.detach().cpu().numpy() for k, p in net.named_parameters()}
 
 
-def assert_grads(got, ref, tol=TOL):
-    """Per-tensor max-norm relative error; tensors whose true gradient is (numerically) zero -- the last
-    bias under a shift-invariant loss -- are compared on the scale of the largest gradient instead."""
+def assert_grads(got, ref, tol=TOL, ref32=None):
+    """The parity metric of SURVEY 8(c): max|delta| / max|ref|, (a) over the whole flat gradient and (b) per
+    parameter tensor.  Parameter gradients are sums over thousands of documents with cancellation, so the
+    reference's OWN fp32 path deviates from exact arithmetic by more than 1e-5 on some small tensors; when
+    the fp32 oracle result `ref32` is given, the per-tensor bar is max(tol, 4 x that fp32 noise).  A tensor
+    whose exact gradient is identically zero (last bias under a shift-invariant loss) holds only noise on
+    both sides: tensors below 1e-3 of the largest gradient are covered by (a) only."""
     top = max(float(np.abs(np.asarray(v)).max()) for v in ref.values())
     for k, v in got.items():
         r = np.asarray(ref[k], dtype=np.float64)
-        scale = max(float(np.abs(r).max()), 1e-4 * top, 1e-30)
-        err = float(np.abs(np.asarray(v, dtype=np.float64) - r).max()) / scale
-        assert err < tol, (k, err)
+        d = float(np.abs(np.asarray(v, dtype=np.float64) - r).max())
+        noise = 0.0 if ref32 is None else 4.0 * float(np.abs(np.asarray(ref32[k], dtype=np.float64) - r).max())
+        assert d / max(top, 1e-30) < max(tol, noise / top), (k, "global", d / top, noise / top)
+        rmax = float(np.abs(r).max())
+        if rmax >= 1e-3 * top:
+            assert d / rmax < max(tol, noise / rmax), (k, d / rmax, noise / rmax)
 
 
 # ------------------------------------------------------------------------------------- golden vectors
@@ -96,16 +103,16 @@ def test_double_golden(dev):
 
 
 # ------------------------------------------------------------------------------------- oracle, fresh inputs
-def _oracle_step(kind, sd, x, y, loss, k1=None, k2=None):
-    """fp64 CPU oracle: loss and parameter gradients by autograd over the restatement."""
-    p = {k: v.double().clone().requires_grad_(True) for k, v in sd.items()}
-    xd = x.double()
+def _oracle_step(kind, sd, x, y, loss, k1=None, k2=None, dtype=torch.float64):
+    """CPU oracle (fp64 by default): loss and parameter gradients by autograd over the restatement."""
+    p = {k: v.to(dtype).clone().requires_grad_(True) for k, v in sd.items()}
+    xd = x.to(dtype)
     if kind == "triple":
         s = O.triple_layer_forward(xd, p)
     else:
-        s = O.double_layer_forward(xd, p, None if k1 is None else k1.double(), None if k2 is None else k2.double())
+        s = O.double_layer_forward(xd, p, None if k1 is None else k1.to(dtype), None if k2 is None else k2.to(dtype))
     s = s.squeeze(-1)
-    l = O.approx_ndcg(s, y.double()) if loss == "approxNDCG" else O.listnet(y.double(), s)
+    l = O.approx_ndcg(s, y.to(dtype)) if loss == "approxNDCG" else O.listnet(y.to(dtype), s)
     l.backward()
     return l.detach().numpy(), {k: v.grad.numpy() for k, v in p.items()}, s.detach().numpy()
 
@@ -137,11 +144,12 @@ def test_fused_step_vs_oracle(kind, S, B, loss, dev):
     else:
         net.eval()
     rl, rg, _ = _oracle_step(kind.split("_")[0], sd, x, y, loss, k1, k2)
+    _, rg32, _ = _oracle_step(kind.split("_")[0], sd, x, y, loss, k1, k2, dtype=torch.float32)
     ranker = FusedRanker(net, loss=loss)
     out = ranker.step(x.to(dev), y.to(dev), keep1=None if k1 is None else k1.to(dev),
                       keep2=None if k2 is None else k2.to(dev))
     assert relerr(out.cpu().numpy(), rl) < TOL
-    assert_grads(_grads(net), rg)
+    assert_grads(_grads(net), rg, ref32=rg32)
     # p.grad aliases the flat buffer, in parameters() order
     flat = torch.cat([p.grad.reshape(-1) for p in net.parameters()])
     assert torch.equal(flat, ranker.flat_grad)
@@ -163,7 +171,10 @@ def test_module_path_any_shape(kind, n_docs, dev):
     assert relerr(out.detach().cpu().numpy(), ref.detach().numpy()) < TOL
     out.backward(gs.to(dev))
     ref.backward(gs.double())
-    assert_grads(_grads(net), {k: v.grad.numpy() for k, v in p.items()})
+    p32 = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    (O.triple_layer_forward if kind == "triple" else O.double_layer_forward)(x, p32).backward(gs)
+    assert_grads(_grads(net), {k: v.grad.numpy() for k, v in p.items()},
+                 ref32={k: v.grad.numpy() for k, v in p32.items()})
 
 
 def test_dropout_stream(dev):
