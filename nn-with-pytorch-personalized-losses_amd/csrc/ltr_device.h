@@ -20,8 +20,8 @@ struct SlateGroup {
     int sp;     // row lanes  = min(nextpow2(S), group)
     int CG;     // column groups = group / sp
     int t;      // thread index inside the group
-    int ri;     // row lane   = t % sp
-    int cg;     // column grp = t / sp
+    int ri;     // row lane   = t / CG
+    int cg;     // column grp = t % CG
     int wig;    // wave index inside the group
     int nw;     // waves per group
     float *part;  // LDS [group]  row-partial scratch
@@ -65,14 +65,33 @@ __device__ __forceinline__ float group_max(const SlateGroup &g, float v) {
 }
 
 // Combine the CG column-group partials of each row: returns sum_c v(row, c) to every replica of the row.
+// The CG replicas of a row are ADJACENT lanes of one wave (t = ri*CG + cg, CG a power of two <= 64), so this
+// is a log2(CG)-step butterfly: no LDS, no barrier, same bits in every replica.
 __device__ __forceinline__ float row_reduce(const SlateGroup &g, float v) {
-    if (g.CG == 1) return v;
+    for (int o = g.CG >> 1; o >= 1; o >>= 1) v += __shfl_xor(v, o, LTR_WAVE);
+    return v;
+}
+
+// Two sums at once through one pair of barriers.
+__device__ __forceinline__ void group_sum2(const SlateGroup &g, float &a, float &b) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+        a += __shfl_xor(a, o, LTR_WAVE);
+        b += __shfl_xor(b, o, LTR_WAVE);
+    }
+    if (g.nw == 1) return;
     __syncthreads();
-    g.part[g.t] = v;
+    if ((threadIdx.x & (LTR_WAVE - 1)) == 0) {
+        g.red[2 * g.wig] = a;
+        g.red[2 * g.wig + 1] = b;
+    }
     __syncthreads();
-    float s = 0.f;
-    for (int c = 0; c < g.CG; ++c) s += g.part[c * g.sp + g.ri];
-    return s;
+    a = 0.f;
+    b = 0.f;
+    for (int w = 0; w < g.nw; ++w) {
+        a += g.red[2 * w];
+        b += g.red[2 * w + 1];
+    }
 }
 
 __host__ __device__ inline int next_pow2(int v) {
@@ -98,8 +117,8 @@ __device__ __forceinline__ SlateGroup make_group(int S, int group, float *scratc
     g.CG = group / g.sp;
     int gid = threadIdx.x / group;
     g.t = threadIdx.x - gid * group;
-    g.ri = g.t & (g.sp - 1);
-    g.cg = g.t / g.sp;
+    g.ri = g.t / g.CG;          // row lane; its CG column groups are adjacent lanes (see row_reduce)
+    g.cg = g.t & (g.CG - 1);
     g.wig = g.t / LTR_WAVE;
     g.nw = group / LTR_WAVE;
     g.part = scratch;

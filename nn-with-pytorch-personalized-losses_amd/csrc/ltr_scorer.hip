@@ -180,15 +180,17 @@ __device__ __forceinline__ void gemm_wx(__amdgpu_buffer_rsrc_t rsrc, int base_by
     }
 }
 
-// Activation (+ dropout) on accumulator tiles; features >= H forced to 0.
+// Activation (+ dropout) on accumulator tiles; features >= H forced to 0 (only the partial last tile needs it).
+// ReLU + Dropout(0.5): 2*max(v,0) AND-ed with a 0 / ~0 mask made from the keep bit (4 VALU ops per value).
 template <int ACT, int H, int NT, int NMAX>
 __device__ __forceinline__ void activate(f32x4 (&h)[NMAX], int q, const PipeArgs &a, int layer, const uint8_t *keep,
                                          long long doc) {
     const bool in_range = doc < a.n_docs;
+    const bool drop = (ACT == ACT_RELU_DROP) && a.dropout;
 #pragma unroll
     for (int To = 0; To < NT; ++To) {
         unsigned kb = 0xFu;
-        if (ACT == ACT_RELU_DROP && a.dropout) {
+        if (drop) {
             if (keep) {
                 const int n0 = 16 * To + 4 * q;
                 unsigned bytes = 0;
@@ -202,24 +204,28 @@ __device__ __forceinline__ void activate(f32x4 (&h)[NMAX], int q, const PipeArgs
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const int n = 16 * To + 4 * q + r;
             float v = h[To][r];
             if (ACT == ACT_RELU_DROP) {
                 v = fmaxf(v, 0.f);
-                if (a.dropout) v = ((kb >> r) & 1u) ? 2.f * v : 0.f;
+                if (drop) {
+                    const int m = ((int)(kb << (31 - r))) >> 31;                  // 0 or ~0
+                    v = __builtin_bit_cast(float, __builtin_bit_cast(int, v + v) & m);
+                }
             } else if (ACT == ACT_SIGMOID) {
-                v = 1.f / (1.f + __expf(-v));
+                v = __frcp_rn(1.f + __expf(-v));
             }
-            h[To][r] = (n < H) ? v : 0.f;
+            if (16 * To + 16 > H) v = (16 * To + 4 * q + r < H) ? v : 0.f;      // compile-time: last tile only
+            h[To][r] = v;
         }
     }
 }
 
+// g * act'(h) with the ReLU/dropout slope (1 or 2, wave-uniform) pre-multiplied into g by the caller.
 template <int ACT>
-__device__ __forceinline__ float act_grad(float h, int dropout) {
-    if (ACT == ACT_RELU_DROP) return h > 0.f ? (dropout ? 2.f : 1.f) : 0.f;
-    if (ACT == ACT_SIGMOID) return h * (1.f - h);
-    return 1.f;
+__device__ __forceinline__ float apply_act_grad(float g, float h) {
+    if (ACT == ACT_RELU_DROP) return h > 0.f ? g : 0.f;
+    if (ACT == ACT_SIGMOID) return g * (h * (1.f - h));
+    return g;
 }
 
 // Per-wave dW tile sets, fixed at compile time.  The NR x NC tile grid is walked in row bands of height BH,
@@ -236,7 +242,6 @@ __host__ __device__ constexpr int dw_col(int g) { return (g % (NC * BH)) / BH; }
 template <int W, int TW, int NR, int NC, int BH, int LD>
 __device__ __forceinline__ void dw_chunk_w(f32x4 (&acc)[TW], const float *a_base, const float *b_base) {
     constexpr int NTOT = NR * NC;
-#pragma unroll 2
     for (int s = 0; s < kChunkDocs / 4; ++s) {
         const float *ar = a_base + s * 4 * LD;
         const float *br = b_base + s * 4 * LD;
@@ -321,7 +326,9 @@ __global__ void __launch_bounds__(kThreads, 2) slate_pipeline_kernel(const PipeA
     float *gn = yl + kTileDocs;               // [128] gains
     float *gg = gn + kTileDocs;               // [128] loss scratch
     float *dsc = gg + kTileDocs;              // [128] d loss / d score
-    float *w3s = dsc + kTileDocs;             // [NT2*16 + 16] w3 (zero padded), b3
+    float *uu = dsc + kTileDocs;              // [128] loss scratch (per-document exponentials)
+    float *mk = uu + kTileDocs;               // [128] loss scratch (valid-document mask)
+    float *w3s = mk + kTileDocs;              // [NT2*16 + 16] w3 (zero padded), b3
     float *dw3 = w3s + N::NT2 * 16 + 16;      // [kWaves][NT2*16] per-wave dw3 accumulators
     float *scratch = dw3 + kWaves * N::NT2 * 16;   // [512 + 4*32] slate-group scratch
 
@@ -445,9 +452,19 @@ __global__ void __launch_bounds__(kThreads, 2) slate_pipeline_kernel(const PipeA
             const int so = gid * a.S;
             const long long slate = (long long)st * (kTileDocs / a.S) + gid;
             float loss;
-            if (a.loss_kind == 0)
-                loss = approx_ndcg_slate(g, sc + so, yl + so, gn + so, gg + so, a.alpha, a.eps, a.gscale, true,
-                                         [&](int i, float v) { dsc[so + i] = v; });
+            if (a.loss_kind == 0) {
+                auto st_ds = [&](int i, float v) { dsc[so + i] = v; };
+                // group = 4 S -> 4 column groups per row: block length S / 4, known at compile time per branch
+                if (a.S == 128)
+                    loss = approx_ndcg_slate<32>(g, sc + so, yl + so, gn + so, gg + so, uu + so, mk + so, a.alpha,
+                                                 a.eps, a.gscale, true, st_ds);
+                else if (a.S == 64)
+                    loss = approx_ndcg_slate<16>(g, sc + so, yl + so, gn + so, gg + so, uu + so, mk + so, a.alpha,
+                                                 a.eps, a.gscale, true, st_ds);
+                else
+                    loss = approx_ndcg_slate<8>(g, sc + so, yl + so, gn + so, gg + so, uu + so, mk + so, a.alpha,
+                                                a.eps, a.gscale, true, st_ds);
+            }
             else
                 loss = listnet_slate(g, yl + so, sc + so, a.apply_sigmoid != 0, a.gscale, true,
                                      [&](int i, float v) { dsc[so + i] = v; });
@@ -455,18 +472,37 @@ __global__ void __launch_bounds__(kThreads, 2) slate_pipeline_kernel(const PipeA
         }
         __syncthreads();
 
+        // ---- pull the NEXT super-tile of X into L2 while this one is in its backward (one dword per 128-B line
+        //      per lane; the value is only kept alive until the end of the iteration so the load is waited for)
+        float pf = 0.f;
+        {
+            const long long nb = (long long)(st + gridDim.x) * kTileDocs;
+            const long long fl = nb * N::F + (long long)tid * 32;          // float index of this lane's line
+            if (st + (int)gridDim.x < a.n_super && fl < a.n_docs * N::F) pf = a.X[fl];
+            constexpr int LINES = (kTileDocs * N::F + 31) / 32;
+            if (tid + kThreads < LINES) {
+                const long long fl2 = fl + (long long)kThreads * 32;
+                if (st + (int)gridDim.x < a.n_super && fl2 < a.n_docs * N::F) pf += a.X[fl2];
+            }
+        }
         // ---- backward through fc3: dw3 += ds * h2 (sum over documents = lanes d), dz2 = ds * w3 * act2'(h2)
         // documents past the end of the batch must not contribute to any gradient
         const float ds0 = gdoc < a.n_docs ? dsc[my_row] : 0.f;
         db3 += wave_allsum((q == 0) ? ds0 : 0.f);
+        const float slope = a.dropout ? 2.f : 1.f;                       // d relu-dropout / dz where it is live
+        const float ds2 = (N::A2 == ACT_RELU_DROP) ? ds0 * slope : ds0;
 #pragma unroll
         for (int To = 0; To < N::NT2; ++To) {
             const f32x4 wv = *reinterpret_cast<const f32x4 *>(w3s + 16 * To + 4 * q);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const float v = row_sum_to_lane15(ds0 * h2[To][r]);
-                if (d == 15) dw3[w * N::NT2 * 16 + 16 * To + 4 * q + r] += v;
-                h2[To][r] = ds0 * wv[r] * act_grad<N::A2>(h2[To][r], a.dropout);
+                // fire-and-forget ds_add_f32 into this wave's private slot: single adder per address, program
+                // order across tiles -> deterministic, and no read-modify-write round trip on the critical path
+                if (d == 15)
+                    __hip_atomic_fetch_add(&dw3[w * N::NT2 * 16 + 16 * To + 4 * q + r], v, __ATOMIC_RELAXED,
+                                           __HIP_MEMORY_SCOPE_WORKGROUP);
+                h2[To][r] = apply_act_grad<N::A2>(ds2 * wv[r], h2[To][r]);
             }
         }
         // h2 now holds dz2.
@@ -497,8 +533,10 @@ __global__ void __launch_bounds__(kThreads, 2) slate_pipeline_kernel(const PipeA
         for (int To = 0; To < N::NT1; ++To)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int n = 16 * To + 4 * q + r;
-                dz1[To][r] = (n < N::H1) ? dz1[To][r] * act_grad<N::A1>(h1[To][r], a.dropout) : 0.f;
+                const float gsc = (N::A1 == ACT_RELU_DROP) ? dz1[To][r] * slope : dz1[To][r];
+                float v = apply_act_grad<N::A1>(gsc, h1[To][r]);
+                if (16 * To + 16 > N::H1) v = (16 * To + 4 * q + r < N::H1) ? v : 0.f;   // last tile only
+                dz1[To][r] = v;
             }
         // ---- dW1 += dz1^T [x | 1]; B operand straight from the X tile in LDS
 #pragma unroll
@@ -513,6 +551,7 @@ __global__ void __launch_bounds__(kThreads, 2) slate_pipeline_kernel(const PipeA
             if (!(a.debug_skip & 2))
                 dw_chunk<N::TW1, N::NT1, N::XT, N::BH1, LD>(w, accW1, Ds + q * LD + d, Xs + (64 * c + q) * LD + d);
         }
+        asm volatile("" ::"v"(pf));   // keep the prefetch load alive (and waited for) until here
     }
 
     if (MODE == MODE_FWD) return;
@@ -601,7 +640,7 @@ __global__ void reduce_grads_kernel(const float *__restrict__ partials, int npar
 
 template <class N>
 constexpr size_t pipeline_lds() {
-    return sizeof(float) * (size_t)(kTileDocs * N::LD + 2 * kChunkDocs * N::LD + 5 * kTileDocs + N::NT2 * 16 + 16 +
+    return sizeof(float) * (size_t)(kTileDocs * N::LD + 2 * kChunkDocs * N::LD + 7 * kTileDocs + N::NT2 * 16 + 16 +
                                     kWaves * N::NT2 * 16 + kThreads + 4 * 32 + 64);
 }
 

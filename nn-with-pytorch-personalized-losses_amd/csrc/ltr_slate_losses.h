@@ -49,65 +49,175 @@ __device__ __forceinline__ float ideal_dcg(const SlateGroup &g, const float *yl,
 // ------------------------------------------------------------------------------------------------
 // approxNDCG (losses/approxNDCG.py:7-53).  Returns the slate loss -sum_i G_i / log2(1 + pos_i) to every
 // thread; if want_grad, calls store(i, gscale * dloss/ds_i) once per document (0 for padded documents).
-// gg: LDS [S] scratch.  gn is overwritten with G (padded marker -1 kept).
-template <class Store>
-__device__ __forceinline__ float approx_ndcg_slate(const SlateGroup &g, const float *sc, const float *yl,
-                                                   float *gn, float *gg, float alpha, float eps, float gscale,
-                                                   bool want_grad, Store store) {
-    const float idcg = ideal_dcg(g, yl, gn, eps, 0);
+// All arrays are LDS, length S rounded up to a multiple of 4 (`s_al`); gg, uu, mk are scratch.
+// gn is read-only here: normalisation by maxDCG is applied to the reduced sums, not per document.
+//
+// Pair sweep: row i belongs to a row lane, the columns j of a row are split into CG CONTIGUOUS blocks (one per
+// column group) so a thread reads its block with 16-byte LDS broadcast loads and runs 4 independent pairs
+// per step.  Fast path (score range alpha*(max-min) <= 160): one exponential PER DOCUMENT,
+//     u_k = exp(alpha (s_k - mid)),   sigmoid(-alpha (s_i - s_j)) = u_j / (u_i + u_j),
+// i.e. one v_rcp per pair and no v_exp.  Wider ranges (where u would leave fp32) take the per-pair exp path.
+typedef float lds_f4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void group_minmax(const SlateGroup &g, float &lo, float &hi) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+        lo = fminf(lo, __shfl_xor(lo, o, LTR_WAVE));
+        hi = fmaxf(hi, __shfl_xor(hi, o, LTR_WAVE));
+    }
+    if (g.nw == 1) return;
     __syncthreads();
+    if ((threadIdx.x & (LTR_WAVE - 1)) == 0) {
+        g.red[2 * g.wig] = lo;
+        g.red[2 * g.wig + 1] = hi;
+    }
+    __syncthreads();
+    lo = g.red[0];
+    hi = g.red[1];
+    for (int w = 1; w < g.nw; ++w) {
+        lo = fminf(lo, g.red[2 * w]);
+        hi = fmaxf(hi, g.red[2 * w + 1]);
+    }
+}
+
+// JB > 0: the caller guarantees every column block is exactly JB documents (S = JB * CG, JB % 4 == 0), so the
+// pair sweeps have compile-time trip counts and unroll fully; JB == 0: general shapes.
+template <int JB = 0, class Store>
+__device__ __forceinline__ float approx_ndcg_slate(const SlateGroup &g, float *sc, float *yl, const float *gn,
+                                                   float *gg, float *uu, float *mk, float alpha, float eps,
+                                                   float gscale, bool want_grad, Store store) {
+    const int s_al = (g.S + 3) & ~3;
+    // contiguous column block of this column group, multiple of 4
+    const int jb = JB > 0 ? JB : ((((g.S + g.CG - 1) / g.CG) + 3) & ~3);
+    const int j0 = g.cg * jb;
+    const int j1 = JB > 0 ? j0 + JB : min(j0 + jb, s_al);
+
+    // score range over the real documents -> fast/slow path (slate-uniform)
+    float lo = INFINITY, hi = -INFINITY;
     for (int j = g.t; j < g.S; j += g.group) {
-        const float v = gn[j];
-        gn[j] = v < 0.f ? -1.f : v / idcg;
+        if (gn[j] >= 0.f) {
+            const float x = alpha * sc[j];
+            lo = fminf(lo, x);
+            hi = fmaxf(hi, x);
+        }
+    }
+    group_minmax(g, lo, hi);
+    const bool fast = (hi - lo) <= 160.f;   // false for NaN too
+    const float mid = 0.5f * (hi + lo);
+    for (int j = g.t; j < s_al; j += g.group) {
+        const bool real = j < g.S && gn[j] >= 0.f;
+        mk[j] = real ? 1.f : 0.f;
+        uu[j] = (real && fast) ? expf(alpha * sc[j] - mid) : 1.f;
+        if (j >= g.S) {
+            sc[j] = 0.f;
+            yl[j] = -INFINITY;
+        }
+        gg[j] = 0.f;
     }
     __syncthreads();
 
+    // One sweep per row: label rank by counting (ideal DCG term, approxNDCG.py:28,43) and the soft rank
     // pos_i = 1 + sum_{j != i, both valid} max(sigmoid(-alpha (s_i - s_j)), eps)            (:47-49)
-    float lossacc = 0.f;
+    float idcg_acc = 0.f, loss_acc = 0.f;
     for (int i0 = 0; i0 < g.S; i0 += g.sp) {
         const int i = i0 + g.ri;
         const bool row = i < g.S;
-        const float si = row ? sc[i] : 0.f;
         const bool vi = row && gn[i] >= 0.f;
-        float p = 0.f;
+        float p = 0.f, cnt = 0.f;
+        if (row) {
+            const float yi = yl[i];
+            float c0 = 0.f, c1 = 0.f, c2 = 0.f, c3 = 0.f;
+#pragma unroll 2
+            for (int j = j0; j < j1; j += 4) {
+                const lds_f4 y = *reinterpret_cast<const lds_f4 *>(yl + j);
+                c0 += ((y[0] > yi) || (y[0] == yi && j + 0 < i)) ? 1.f : 0.f;
+                c1 += ((y[1] > yi) || (y[1] == yi && j + 1 < i)) ? 1.f : 0.f;
+                c2 += ((y[2] > yi) || (y[2] == yi && j + 2 < i)) ? 1.f : 0.f;
+                c3 += ((y[3] > yi) || (y[3] == yi && j + 3 < i)) ? 1.f : 0.f;
+            }
+            cnt = (c0 + c1) + (c2 + c3);
+        }
         if (vi) {
-            for (int j = g.cg; j < g.S; j += g.CG) {
-                const float e = __expf(alpha * (si - sc[j]));
-                const float c = fmaxf(__frcp_rn(1.f + e), eps);
-                p += (j != i && gn[j] >= 0.f) ? c : 0.f;
+            if (fast) {
+                const float ui = uu[i];
+                float p0 = 0.f, p1 = 0.f, p2 = 0.f, p3 = 0.f;
+#pragma unroll 2
+                for (int j = j0; j < j1; j += 4) {
+                    const lds_f4 u = *reinterpret_cast<const lds_f4 *>(uu + j);
+                    const lds_f4 m = *reinterpret_cast<const lds_f4 *>(mk + j);
+                    p0 = fmaf(m[0], fmaxf(u[0] * __frcp_rn(ui + u[0]), eps), p0);
+                    p1 = fmaf(m[1], fmaxf(u[1] * __frcp_rn(ui + u[1]), eps), p1);
+                    p2 = fmaf(m[2], fmaxf(u[2] * __frcp_rn(ui + u[2]), eps), p2);
+                    p3 = fmaf(m[3], fmaxf(u[3] * __frcp_rn(ui + u[3]), eps), p3);
+                }
+                p = (p0 + p1) + (p2 + p3);
+                if (i >= j0 && i < j1) p -= fmaxf(ui * __frcp_rn(ui + ui), eps);   // the j == i term
+            } else {
+                const float si = sc[i];
+                for (int j = j0; j < j1; ++j) {
+                    const float e = __expf(alpha * (si - sc[j]));
+                    const float c = fmaxf(__frcp_rn(1.f + e), eps);
+                    p += (j != i && mk[j] != 0.f) ? c : 0.f;
+                }
             }
         }
+        const float r = row_reduce(g, cnt);
         const float pos = 1.f + row_reduce(g, p);
-        if (row && g.cg == 0) {
-            const float Gi = vi ? gn[i] : 0.f;
+        if (vi && g.cg == 0) {
+            const float gain = gn[i];
             const float L = log2f(1.f + pos);
-            lossacc += Gi / L;
-            gg[i] = Gi / (L * L * (1.f + pos) * LTR_LN2) * gscale;   // g_i = d loss / d pos_i
+            if (gain > 0.f) idcg_acc += gain / log2f(2.f + r);
+            loss_acc += gain / L;
+            gg[i] = gain / (L * L * (1.f + pos) * LTR_LN2);      // d(-sum gain/L)/d pos_i, not yet / maxDCG
         }
     }
-    const float total = group_sum(g, lossacc);
+    group_sum2(g, idcg_acc, loss_acc);     // its barriers also publish gg
+    const float inv_idcg = 1.f / fmaxf(idcg_acc, eps);          // maxDCG clamp (:43)
+    const float total = loss_acc * inv_idcg;
     if (!want_grad) return -total;
-    __syncthreads();  // gg complete
+    if (g.nw == 1) __syncthreads();
 
     // d loss / d s_k = alpha * sum_j t_kj (g_j [c_jk >= eps] - g_k [c_kj >= eps]),  t = c_kj c_jk
+    const float kscale = alpha * gscale * inv_idcg;
     for (int i0 = 0; i0 < g.S; i0 += g.sp) {
         const int k = i0 + g.ri;
         const bool row = k < g.S;
-        const float sk = row ? sc[k] : 0.f;
         const bool vk = row && gn[k] >= 0.f;
-        const float gk = row ? gg[k] : 0.f;
         float a = 0.f;
         if (vk) {
-            for (int j = g.cg; j < g.S; j += g.CG) {
-                const float e = __expf(alpha * (sk - sc[j]));
-                const float ckj = __frcp_rn(1.f + e);                 // sigmoid(-alpha (s_k - s_j))
-                const float cjk = (e < 1e30f) ? e * ckj : 1.f;        // sigmoid(-alpha (s_j - s_k))
-                const float term = (cjk >= eps ? gg[j] : 0.f) - (ckj >= eps ? gk : 0.f);
-                a += (j != k && gn[j] >= 0.f) ? ckj * cjk * term : 0.f;
+            const float gk = gg[k];
+            if (fast) {
+                const float uk = uu[k];
+                float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+#pragma unroll 2
+                for (int j = j0; j < j1; j += 4) {
+                    const lds_f4 u = *reinterpret_cast<const lds_f4 *>(uu + j);
+                    const lds_f4 m = *reinterpret_cast<const lds_f4 *>(mk + j);
+                    const lds_f4 gj = *reinterpret_cast<const lds_f4 *>(gg + j);
+#define LTR_PAIR(e, acc)                                                            \
+    {                                                                               \
+        const float r = __frcp_rn(uk + u[e]);                                       \
+        const float ckj = u[e] * r, cjk = uk * r;                                   \
+        const float term = (cjk >= eps ? gj[e] : 0.f) - (ckj >= eps ? gk : 0.f);    \
+        acc = fmaf(m[e] * (ckj * cjk), term, acc);                                  \
+    }
+                    LTR_PAIR(0, a0) LTR_PAIR(1, a1) LTR_PAIR(2, a2) LTR_PAIR(3, a3)
+#undef LTR_PAIR
+                }
+                a = (a0 + a1) + (a2 + a3);      // j == k contributes exactly 0 (term = g_k - g_k)
+            } else {
+                const float sk = sc[k];
+                for (int j = j0; j < j1; ++j) {
+                    const float e = __expf(alpha * (sk - sc[j]));
+                    const float ckj = __frcp_rn(1.f + e);                 // sigmoid(-alpha (s_k - s_j))
+                    const float cjk = (e < 1e30f) ? e * ckj : 1.f;        // sigmoid(-alpha (s_j - s_k))
+                    const float term = (cjk >= eps ? gg[j] : 0.f) - (ckj >= eps ? gk : 0.f);
+                    a += (j != k && mk[j] != 0.f) ? ckj * cjk * term : 0.f;
+                }
             }
         }
         const float tot = row_reduce(g, a);
-        if (row && g.cg == 0) store(k, vk ? alpha * tot : 0.f);
+        if (row && g.cg == 0) store(k, vk ? kscale * tot : 0.f);
     }
     return -total;
 }
