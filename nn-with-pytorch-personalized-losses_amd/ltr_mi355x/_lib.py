@@ -4,7 +4,8 @@ import os
 from ctypes import c_char_p, c_float, c_int, c_int64, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_SO = os.path.join(_HERE, "libltr_mi355x.so")
+# LTR_LIB: alternative build of the same ABI (kernel A/B experiments); default is the in-tree library.
+_SO = os.environ.get("LTR_LIB") or os.path.join(_HERE, "libltr_mi355x.so")
 
 
 class LtrError(RuntimeError):
