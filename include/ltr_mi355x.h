@@ -156,6 +156,15 @@ int ltr_fused_step(int net, int loss_kind, const float *X, const float *labels, 
                    float pad, int apply_sigmoid, float grad_scale, float *slate_loss, float *partials, int grid,
                    void *stream);
 
+/* The same fused pass with lambdaLoss (losses/lambdaL.py:67-93; the loss main_batch_execution.py:135 trains
+ * with: weighing_scheme="ndcgLoss2PP_scheme").  scheme/k/sigma/mu/eps/log_base as in ltr_lambda_fwd_bwd;
+ * slate_loss[b] = -sum of the kept pair terms, slate_count[b] (may be NULL) = kept pairs.  reduction="sum":
+ * grad_scale = 1; a "mean" is obtained by dividing loss and flat gradient by the (global) pair count. */
+int ltr_fused_step_lambda(int net, const float *X, const float *labels, int B, int S, const float *packed, int dropout,
+                          uint64_t seed, const uint8_t *keep1, const uint8_t *keep2, int scheme, int k, float sigma,
+                          float mu, float eps, float pad, int log_base, float grad_scale, float *slate_loss,
+                          float *slate_count, float *partials, int grid, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

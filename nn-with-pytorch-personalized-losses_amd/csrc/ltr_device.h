@@ -28,17 +28,54 @@ struct SlateGroup {
     float *red;   // LDS [32]     cross-wave scratch
 };
 
+#ifndef LTR_DPP_REDUCE
+#define LTR_DPP_REDUCE 1
+#endif
+
+// Cross-lane moves inside a 16-lane DPP row (VALU, no LDS crossbar): quad xor-1, quad xor-2, half-row mirror
+// (i <-> 7-i), row mirror (i <-> 15-i).  Each step pairs lanes SYMMETRICALLY, so after the four steps all 16
+// lanes of a row hold bit-identical results for any commutative op.
+#define LTR_DPP(x, ctrl) \
+    __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), ctrl, 0xF, 0xF, false))
+#define LTR_DPP_XOR1 0xB1
+#define LTR_DPP_XOR2 0x4E
+#define LTR_DPP_HALF_MIRROR 0x141
+#define LTR_DPP_MIRROR 0x140
+
+__device__ __forceinline__ float lane_bcast(float v, int lane) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), lane));
+}
+
+// All-lanes wave reductions; every lane ends with the same bits (replicated control flow depends on it).
 __device__ __forceinline__ float wave_allsum(float v) {
+#if LTR_DPP_REDUCE
+    v += LTR_DPP(v, LTR_DPP_XOR1);
+    v += LTR_DPP(v, LTR_DPP_XOR2);
+    v += LTR_DPP(v, LTR_DPP_HALF_MIRROR);
+    v += LTR_DPP(v, LTR_DPP_MIRROR);
+    return (lane_bcast(v, 0) + lane_bcast(v, 16)) + (lane_bcast(v, 32) + lane_bcast(v, 48));
+#else
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, LTR_WAVE);
     return v;  // butterfly: every lane holds the same bits
+#endif
 }
 
 __device__ __forceinline__ float wave_allmax(float v) {
+#if LTR_DPP_REDUCE
+    v = fmaxf(v, LTR_DPP(v, LTR_DPP_XOR1));
+    v = fmaxf(v, LTR_DPP(v, LTR_DPP_XOR2));
+    v = fmaxf(v, LTR_DPP(v, LTR_DPP_HALF_MIRROR));
+    v = fmaxf(v, LTR_DPP(v, LTR_DPP_MIRROR));
+    return fmaxf(fmaxf(lane_bcast(v, 0), lane_bcast(v, 16)), fmaxf(lane_bcast(v, 32), lane_bcast(v, 48)));
+#else
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, LTR_WAVE));
     return v;
+#endif
 }
+
+__device__ __forceinline__ float wave_allmin(float v) { return -wave_allmax(-v); }
 
 // Sum over all threads of the slate group; every thread gets the total.  All threads of the BLOCK must
 // call it (uniform __syncthreads count).
@@ -68,17 +105,23 @@ __device__ __forceinline__ float group_max(const SlateGroup &g, float v) {
 // The CG replicas of a row are ADJACENT lanes of one wave (t = ri*CG + cg, CG a power of two <= 64), so this
 // is a log2(CG)-step butterfly: no LDS, no barrier, same bits in every replica.
 __device__ __forceinline__ float row_reduce(const SlateGroup &g, float v) {
+#if LTR_DPP_REDUCE
+    if (g.CG <= 16) {   // group-uniform
+        if (g.CG >= 2) v += LTR_DPP(v, LTR_DPP_XOR1);
+        if (g.CG >= 4) v += LTR_DPP(v, LTR_DPP_XOR2);
+        if (g.CG >= 8) v += LTR_DPP(v, LTR_DPP_HALF_MIRROR);
+        if (g.CG >= 16) v += LTR_DPP(v, LTR_DPP_MIRROR);
+        return v;
+    }
+#endif
     for (int o = g.CG >> 1; o >= 1; o >>= 1) v += __shfl_xor(v, o, LTR_WAVE);
     return v;
 }
 
 // Two sums at once through one pair of barriers.
 __device__ __forceinline__ void group_sum2(const SlateGroup &g, float &a, float &b) {
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) {
-        a += __shfl_xor(a, o, LTR_WAVE);
-        b += __shfl_xor(b, o, LTR_WAVE);
-    }
+    a = wave_allsum(a);
+    b = wave_allsum(b);
     if (g.nw == 1) return;
     __syncthreads();
     if ((threadIdx.x & (LTR_WAVE - 1)) == 0) {

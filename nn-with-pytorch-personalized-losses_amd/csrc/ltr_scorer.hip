@@ -23,6 +23,7 @@
 //     (no float atomics: bit-reproducible gradients).
 #include "../../include/ltr_mi355x.h"
 #include "ltr_slate_losses.h"
+#include <math.h>
 #include <stdlib.h>
 
 using namespace ltr;
@@ -36,6 +37,12 @@ constexpr int kWaves = 8;        // 2 waves per SIMD: the co-resident wave hides
 constexpr int kThreads = kWaves * 64;
 constexpr int kChunkDocs = 64;   // documents per dW staging chunk (the 16-doc tiles of 4 waves)
 constexpr int kRing = 6;         // weight fragments kept in flight per wave (1 KiB each, L2 -> registers)
+// Next-X-tile prefetch policy, per kernel instantiation (A/B on MI355X, profiles/r01_variant_ab.json):
+//   registers (36 VGPRs live across the loop) where they are free: forward-only kernels -8..-19 %, the 136-64-32
+//   net's fused kernel -4 %;  L2-only prefetch (one dword per 128-B line) for the 136-136-136 backward/fused
+//   kernels, where 36 more live registers spill and cost +11 %.
+template <class N, int MODE>
+__host__ __device__ constexpr bool x_reg_prefetch() { return MODE == 0 /*MODE_FWD*/ || N::H1 <= 64; }
 
 enum { ACT_ID = 0, ACT_RELU_DROP = 1, ACT_SIGMOID = 2 };
 enum { MODE_FWD = 0, MODE_BWD = 1, MODE_FUSED = 2 };
@@ -87,7 +94,9 @@ struct PipeArgs {
     const uint8_t *keep2;
     unsigned long long seed;
     int dropout;             // 1: training-mode dropout p = 0.5 on ACT_RELU_DROP layers
-    int loss_kind;           // 0 approxNDCG, 1 ListNet
+    int loss_kind;           // 0 approxNDCG, 1 ListNet, 2 LambdaLoss
+    LambdaParams lp;         // loss_kind 2
+    float *slate_count;      // loss_kind 2: kept pairs per slate (may be NULL)
     float alpha, eps, pad, gscale;
     int apply_sigmoid;
     int n_super;
@@ -314,7 +323,27 @@ __device__ __forceinline__ void dw_store(int w, const f32x4 (&acc)[TW], float *d
     }
 }
 
-template <class N, int MODE>
+// LOSS (MODE_FUSED only): 0 approxNDCG, 1 ListNet, 2 LambdaLoss -- a template parameter so that each fused
+// kernel carries only its own loss code (sharing one kernel cost the approxNDCG path 2 % in registers/code).
+// This wave's 16 documents of a super-tile: kXV4 float4 per lane, zeros past the end of the batch.
+template <class N>
+__host__ __device__ constexpr int kXV4() { return (16 * (N::F / 4) + 63) / 64; }
+
+template <class N>
+__device__ __forceinline__ void load_x_tile(f32x4 (&xr)[kXV4<N>()], const PipeArgs &a, long long row0, int lane) {
+    constexpr int V4_PER_ROW = N::F / 4;
+    constexpr int V4 = 16 * V4_PER_ROW;
+    const f32x4 *src = reinterpret_cast<const f32x4 *>(a.X + row0 * N::F);
+#pragma unroll
+    for (int m = 0; m < kXV4<N>(); ++m) {
+        const int e = lane + 64 * m;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (e < V4 && row0 + e / V4_PER_ROW < a.n_docs) v = src[e];
+        xr[m] = v;
+    }
+}
+
+template <class N, int MODE, int LOSS>
 __global__ void __launch_bounds__(kThreads, 2) slate_pipeline_kernel(const PipeArgs a) {
     constexpr int LD = N::LD;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -328,7 +357,8 @@ __global__ void __launch_bounds__(kThreads, 2) slate_pipeline_kernel(const PipeA
     float *dsc = gg + kTileDocs;              // [128] d loss / d score
     float *uu = dsc + kTileDocs;              // [128] loss scratch (per-document exponentials)
     float *mk = uu + kTileDocs;               // [128] loss scratch (valid-document mask)
-    float *w3s = mk + kTileDocs;              // [NT2*16 + 16] w3 (zero padded), b3
+    float *xt = mk + kTileDocs;               // [128] loss scratch (LambdaLoss ranks)
+    float *w3s = xt + kTileDocs;              // [NT2*16 + 16] w3 (zero padded), b3
     float *dw3 = w3s + N::NT2 * 16 + 16;      // [kWaves][NT2*16] per-wave dw3 accumulators
     float *scratch = dw3 + kWaves * N::NT2 * 16;   // [512 + 4*32] slate-group scratch
 
@@ -356,23 +386,23 @@ __global__ void __launch_bounds__(kThreads, 2) slate_pipeline_kernel(const PipeA
     const int chunk = w >> 2;                              // dW chunk this wave's tile belongs to
     const int crow = 16 * (w & 3) + d;                     // ... and its row inside the chunk
 
+    constexpr bool XPREF = x_reg_prefetch<N, MODE>();
+    f32x4 xn[kXV4<N>()];
     for (int st = blockIdx.x; st < a.n_super; st += gridDim.x) {
         const long long doc_base = (long long)st * kTileDocs;
         __syncthreads();   // previous super-tile done with Xs / sc / dsc
         // ---- X: HBM -> LDS, coalesced 16 B per lane; the wave's 16 documents are contiguous in memory.
         {
+            // register-prefetch kernels: only the first tile is loaded here, later ones arrive ahead of time
+            if (!XPREF || st == (int)blockIdx.x) load_x_tile<N>(xn, a, doc_base + 16 * w, lane);
             constexpr int V4_PER_ROW = N::F / 4;
             constexpr int V4 = 16 * V4_PER_ROW;             // float4s per wave
-            const long long row0 = doc_base + 16 * w;
-            const f32x4 *src = reinterpret_cast<const f32x4 *>(a.X + row0 * N::F);
 #pragma unroll
-            for (int m = 0; m < (V4 + 63) / 64; ++m) {
+            for (int m = 0; m < kXV4<N>(); ++m) {
                 const int e = lane + 64 * m;
                 if (e < V4) {
                     const int r = e / V4_PER_ROW, c4 = e - r * V4_PER_ROW;
-                    f32x4 v = {0.f, 0.f, 0.f, 0.f};
-                    if (row0 + r < a.n_docs) v = src[e];
-                    *reinterpret_cast<f32x4 *>(Xs + (16 * w + r) * LD + 4 * c4) = v;
+                    *reinterpret_cast<f32x4 *>(Xs + (16 * w + r) * LD + 4 * c4) = xn[m];
                 }
             }
             // ones feature at column F, zeros up to LD
@@ -387,7 +417,7 @@ __global__ void __launch_bounds__(kThreads, 2) slate_pipeline_kernel(const PipeA
         if (MODE == MODE_FUSED && tid < kTileDocs) {
             const long long doc = doc_base + tid;
             const float y = doc < (long long)a.B * a.S ? a.labels[doc] : a.pad;
-            if (a.loss_kind == 0) stage_label(y, a.pad, yl[tid], gn[tid]);
+            if (LOSS != 1) stage_label(y, a.pad, yl[tid], gn[tid]);
             else yl[tid] = doc < (long long)a.B * a.S ? y : 0.f;
         }
         if (MODE == MODE_BWD && tid < kTileDocs) {
@@ -397,6 +427,10 @@ __global__ void __launch_bounds__(kThreads, 2) slate_pipeline_kernel(const PipeA
         __syncthreads();
 
         const long long gdoc = doc_base + my_row;
+        // forward-only kernels never reach the backward's prefetch point: fetch the next X slice here, it lands
+        // during fc1/fc2 (xn was copied to LDS above)
+        if (MODE == MODE_FWD && XPREF && st + (int)gridDim.x < a.n_super)
+            load_x_tile<N>(xn, a, (long long)(st + gridDim.x) * kTileDocs + 16 * w, lane);
         // ---- fc1
         f32x4 h1[N::H1T];
         {
@@ -452,7 +486,7 @@ __global__ void __launch_bounds__(kThreads, 2) slate_pipeline_kernel(const PipeA
             const int so = gid * a.S;
             const long long slate = (long long)st * (kTileDocs / a.S) + gid;
             float loss;
-            if (a.loss_kind == 0) {
+            if (LOSS == 0) {
                 auto st_ds = [&](int i, float v) { dsc[so + i] = v; };
                 // group = 4 S -> 4 column groups per row: block length S / 4, known at compile time per branch
                 if (a.S == 128)
@@ -465,9 +499,17 @@ __global__ void __launch_bounds__(kThreads, 2) slate_pipeline_kernel(const PipeA
                     loss = approx_ndcg_slate<8>(g, sc + so, yl + so, gn + so, gg + so, uu + so, mk + so, a.alpha,
                                                 a.eps, a.gscale, true, st_ds);
             }
-            else
+            else if (LOSS == 1)
                 loss = listnet_slate(g, yl + so, sc + so, a.apply_sigmoid != 0, a.gscale, true,
                                      [&](int i, float v) { dsc[so + i] = v; });
+            else {
+                LambdaLds L;
+                L.sc = sc + so; L.yl = yl + so; L.gn = gn + so; L.w1 = gg + so; L.invd = uu + so; L.delta = mk + so;
+                L.rk = reinterpret_cast<int *>(xt + so);
+                float count;
+                loss = lambda_slate<-1>(g, L, a.lp, a.gscale, true, &count, [&](int i, float v) { dsc[so + i] = v; });
+                if (g.t == 0 && slate < a.B && a.slate_count) a.slate_count[slate] = count;
+            }
             if (g.t == 0 && slate < a.B) a.slate_loss[slate] = loss;
         }
         __syncthreads();
@@ -475,7 +517,7 @@ __global__ void __launch_bounds__(kThreads, 2) slate_pipeline_kernel(const PipeA
         // ---- pull the NEXT super-tile of X into L2 while this one is in its backward (one dword per 128-B line
         //      per lane; the value is only kept alive until the end of the iteration so the load is waited for)
         float pf = 0.f;
-        {
+        if (!XPREF) {
             const long long nb = (long long)(st + gridDim.x) * kTileDocs;
             const long long fl = nb * N::F + (long long)tid * 32;          // float index of this lane's line
             if (st + (int)gridDim.x < a.n_super && fl < a.n_docs * N::F) pf = a.X[fl];
@@ -538,6 +580,9 @@ __global__ void __launch_bounds__(kThreads, 2) slate_pipeline_kernel(const PipeA
                 if (16 * To + 16 > N::H1) v = (16 * To + 4 * q + r < N::H1) ? v : 0.f;   // last tile only
                 dz1[To][r] = v;
             }
+        // next super-tile's X slice -> registers now (h1/h2 are dead); it lands during the dW1 MFMAs below
+        if (MODE != MODE_FWD && XPREF && st + (int)gridDim.x < a.n_super)
+            load_x_tile<N>(xn, a, (long long)(st + gridDim.x) * kTileDocs + 16 * w, lane);
         // ---- dW1 += dz1^T [x | 1]; B operand straight from the X tile in LDS
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
@@ -640,7 +685,7 @@ __global__ void reduce_grads_kernel(const float *__restrict__ partials, int npar
 
 template <class N>
 constexpr size_t pipeline_lds() {
-    return sizeof(float) * (size_t)(kTileDocs * N::LD + 2 * kChunkDocs * N::LD + 7 * kTileDocs + N::NT2 * 16 + 16 +
+    return sizeof(float) * (size_t)(kTileDocs * N::LD + 2 * kChunkDocs * N::LD + 8 * kTileDocs + N::NT2 * 16 + 16 +
                                     kWaves * N::NT2 * 16 + kThreads + 4 * 32 + 64);
 }
 
@@ -649,26 +694,31 @@ inline int status() {
     return e == hipSuccess ? LTR_OK : (int)e;
 }
 
-template <class N, int MODE>
+template <class N, int MODE, int LOSS>
 int launch_pipeline(const PipeArgs &a, int grid, hipStream_t stream) {
     constexpr size_t lds = pipeline_lds<N>();
     static bool attr_done = false;
     if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute((const void *)slate_pipeline_kernel<N, MODE>,
+        hipError_t e = hipFuncSetAttribute((const void *)slate_pipeline_kernel<N, MODE, LOSS>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
         attr_done = true;
     }
-    hipLaunchKernelGGL((slate_pipeline_kernel<N, MODE>), dim3(grid), dim3(kThreads), lds, stream, a);
+    hipLaunchKernelGGL((slate_pipeline_kernel<N, MODE, LOSS>), dim3(grid), dim3(kThreads), lds, stream, a);
     return status();
 }
 
 template <class N>
 int pipeline_dispatch(int mode, const PipeArgs &a, int grid, hipStream_t stream) {
     switch (mode) {
-        case MODE_FWD: return launch_pipeline<N, MODE_FWD>(a, grid, stream);
-        case MODE_BWD: return launch_pipeline<N, MODE_BWD>(a, grid, stream);
-        default: return launch_pipeline<N, MODE_FUSED>(a, grid, stream);
+        case MODE_FWD: return launch_pipeline<N, MODE_FWD, 0>(a, grid, stream);
+        case MODE_BWD: return launch_pipeline<N, MODE_BWD, 0>(a, grid, stream);
+        default:
+            switch (a.loss_kind) {
+                case 0: return launch_pipeline<N, MODE_FUSED, 0>(a, grid, stream);
+                case 1: return launch_pipeline<N, MODE_FUSED, 1>(a, grid, stream);
+                default: return launch_pipeline<N, MODE_FUSED, 2>(a, grid, stream);
+            }
     }
 }
 
@@ -798,6 +848,36 @@ int ltr_fused_step(int net, int loss_kind, const float *X, const float *labels, 
     a.pad = pad;
     a.gscale = grad_scale;
     a.apply_sigmoid = apply_sigmoid;
+    return net == LTR_NET_DOUBLE ? pipeline_dispatch<DoubleNet>(MODE_FUSED, a, grid, (hipStream_t)stream)
+                                 : pipeline_dispatch<TripleNet>(MODE_FUSED, a, grid, (hipStream_t)stream);
+}
+
+int ltr_fused_step_lambda(int net, const float *X, const float *labels, int B, int S, const float *packed, int dropout,
+                          uint64_t seed, const uint8_t *keep1, const uint8_t *keep2, int scheme, int k, float sigma,
+                          float mu, float eps, float pad, int log_base, float grad_scale, float *slate_loss,
+                          float *slate_count, float *partials, int grid, void *stream) {
+    PipeArgs a;
+    if (B < 0 || (S != 32 && S != 64 && S != 128)) return LTR_ERR_SHAPE;
+    if (int rc = fill_common(a, net, X, (int64_t)B * S, packed, dropout, seed, keep1, keep2)) return rc;
+    if (!labels || !slate_loss || !partials) return LTR_ERR_NULL;
+    if (scheme < 0 || scheme > 7 || (log_base != LTR_LOG_BINARY && log_base != LTR_LOG_NATURAL) || !(eps > 0.f) || grid < 1)
+        return LTR_ERR_PARAM;
+    a.labels = labels;
+    a.B = B;
+    a.S = S;
+    a.slate_loss = slate_loss;
+    a.slate_count = slate_count;
+    a.partials = partials;
+    a.loss_kind = 2;
+    a.pad = pad;
+    a.gscale = grad_scale;
+    a.lp.scheme = scheme;
+    a.lp.k = k;
+    a.lp.sigma = sigma;
+    a.lp.mu = mu;
+    a.lp.eps = eps;
+    a.lp.log_scale = log_base == LTR_LOG_BINARY ? (float)(1.0 / 0.693147180559945309417) : 1.f;
+    a.lp.log_floor = log_base == LTR_LOG_BINARY ? log2f(eps) : logf(eps);
     return net == LTR_NET_DOUBLE ? pipeline_dispatch<DoubleNet>(MODE_FUSED, a, grid, (hipStream_t)stream)
                                  : pipeline_dispatch<TripleNet>(MODE_FUSED, a, grid, (hipStream_t)stream);
 }

@@ -60,11 +60,8 @@ __device__ __forceinline__ float ideal_dcg(const SlateGroup &g, const float *yl,
 typedef float lds_f4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ void group_minmax(const SlateGroup &g, float &lo, float &hi) {
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) {
-        lo = fminf(lo, __shfl_xor(lo, o, LTR_WAVE));
-        hi = fmaxf(hi, __shfl_xor(hi, o, LTR_WAVE));
-    }
+    lo = wave_allmin(lo);
+    hi = wave_allmax(hi);
     if (g.nw == 1) return;
     __syncthreads();
     if ((threadIdx.x & (LTR_WAVE - 1)) == 0) {
@@ -327,22 +324,25 @@ __device__ __forceinline__ void lambda_prepare(const SlateGroup &g, const Lambda
 }
 
 // Pair weight w_ij (first element i, second j), lambdaL.py:96-127.  Gi/Gj are 0 for padded documents.
+// SCH >= 0: scheme fixed at compile time (standalone kernels); SCH < 0: taken from P.scheme at run time
+// (slate-uniform branches; used inside the fused pipeline kernel, which is too large to instantiate 8 times).
 template <int SCH>
 __device__ __forceinline__ float lambda_weight(const LambdaLds &L, const LambdaParams &P, int i, int j, float Gi,
                                                float Gj, float yci, float ycj) {
-    if (SCH == 0 || SCH == 5) return 1.f;
-    if (SCH == 1) return L.w1[i];
-    if (SCH == 6) return fabsf(yci - ycj);
-    if (SCH == 7) return fabsf(yci * yci - ycj * ycj);
+    const int sch = SCH < 0 ? P.scheme : SCH;
+    if (sch == 0 || sch == 5) return 1.f;
+    if (sch == 1) return L.w1[i];
+    if (sch == 6) return fabsf(yci - ycj);
+    if (sch == 7) return fabsf(yci * yci - ycj * ycj);
     const float dG = fabsf(Gi - Gj);
     float w = 0.f;
-    if (SCH == 2 || SCH == 4) {
+    if (sch == 2 || sch == 4) {
         int m = L.rk[i] - L.rk[j];
         m = m < 0 ? -m : m;
         w = L.delta[m] * dG;
-        if (SCH == 4) w *= P.mu;
+        if (sch == 4) w *= P.mu;
     }
-    if (SCH == 3 || SCH == 4) w += fabsf(L.invd[i] - L.invd[j]) * dG;
+    if (sch == 3 || sch == 4) w += fabsf(L.invd[i] - L.invd[j]) * dG;
     return w;
 }
 
@@ -383,9 +383,10 @@ __device__ __forceinline__ float lambda_slate(const SlateGroup &g, const LambdaL
                 sigmoid_pair(P.sigma * d, u, um);
                 const float ycj = fmaxf(yj, 0.f);
                 // pair (i, j): i first.  ndcgLoss1 keeps every valid pair incl. the diagonal (:26-27).
-                const bool caseA = ok && (SCH == 1 || yi > yj);
+                const bool all_pairs = (SCH < 0 ? P.scheme : SCH) == 1;
+                const bool caseA = ok && (all_pairs || yi > yj);
                 // pair (j, i): i second (gradient only; its loss term is counted by thread j).
-                const bool caseB = ok && j != i && (SCH == 1 || yj > yi);
+                const bool caseB = ok && j != i && (all_pairs || yj > yi);
                 if (caseA) {
                     float ell, dl;
                     lambda_pair_term(P, lambda_weight<SCH>(L, P, i, j, Gi, fmaxf(Gj, 0.f), yci, ycj), u, um, ell, dl);

@@ -16,7 +16,7 @@ from ._lib import LtrError, check, lib
 from .functional import _ptr, _stream, require_device
 
 NET_DOUBLE, NET_TRIPLE = 0, 1
-LOSS_APPROXNDCG, LOSS_LISTNET = 0, 1
+LOSS_APPROXNDCG, LOSS_LISTNET, LOSS_LAMBDA = 0, 1, 2
 _MASK64 = (1 << 64) - 1
 
 
@@ -166,10 +166,11 @@ class FusedRanker:
     `grad_div` rescales the mean-type losses for a global batch (B_global = B * world_size).
     """
 
-    LOSSES = {"approxNDCG": LOSS_APPROXNDCG, "listnet": LOSS_LISTNET}
+    LOSSES = {"approxNDCG": LOSS_APPROXNDCG, "listnet": LOSS_LISTNET, "lambdaLoss": LOSS_LAMBDA}
 
     def __init__(self, module, loss="approxNDCG", alpha=1.0, eps=1e-10, padded_value_indicator=-1,
-                 apply_sigmoid=False, grid=None):
+                 apply_sigmoid=False, grid=None, weighing_scheme=None, k=None, sigma=1.0, mu=10.0,
+                 reduction="sum", reduction_log="binary"):
         if loss not in self.LOSSES:
             raise KeyError(f"fused loss must be one of {sorted(self.LOSSES)}, got {loss!r}")
         self.module = module
@@ -179,6 +180,14 @@ class FusedRanker:
         self.loss_kind = self.LOSSES[loss]
         self.alpha, self.eps, self.pad = float(alpha), float(eps), float(padded_value_indicator)
         self.apply_sigmoid = bool(apply_sigmoid)
+        if self.loss_kind == LOSS_LAMBDA:
+            from .functional import _lambda_args
+            if reduction == "mean":
+                raise NotImplementedError('fused lambdaLoss supports reduction="sum" (the reference default); '
+                                          'use losses.lambdaL.lambdaLoss for "mean"')
+            if reduction != "sum":
+                raise ValueError("Reduction method can be either sum or mean")
+            self.lambda_args = _lambda_args(eps, padded_value_indicator, weighing_scheme, k, sigma, mu, reduction_log)
         self.params = module._ltr_params()
         require_device(*self.params)
         dev = self.params[0].device
@@ -226,10 +235,17 @@ class FusedRanker:
             h = lib()
             if self.kernel_events is not None:
                 self.kernel_events[0].record()
-            check(h.ltr_fused_step(self.net, self.loss_kind, _ptr(x2), _ptr(yy), B, S, _ptr(self.packed), int(dropout),
-                                   int(seed) & _MASK64, _ptr(k1), _ptr(k2), self.alpha, self.eps, self.pad,
-                                   int(self.apply_sigmoid), scale, _ptr(self._slate), _ptr(self.partials), self.grid,
-                                   _stream()), "ltr_fused_step")
+            if self.loss_kind == LOSS_LAMBDA:
+                sid, kk, sigma, mu, eps, pad, lb = self.lambda_args
+                check(h.ltr_fused_step_lambda(self.net, _ptr(x2), _ptr(yy), B, S, _ptr(self.packed), int(dropout),
+                                              int(seed) & _MASK64, _ptr(k1), _ptr(k2), sid, kk, sigma, mu, eps, pad,
+                                              lb, 1.0, _ptr(self._slate), None, _ptr(self.partials), self.grid,
+                                              _stream()), "ltr_fused_step_lambda")
+            else:
+                check(h.ltr_fused_step(self.net, self.loss_kind, _ptr(x2), _ptr(yy), B, S, _ptr(self.packed),
+                                       int(dropout), int(seed) & _MASK64, _ptr(k1), _ptr(k2), self.alpha, self.eps,
+                                       self.pad, int(self.apply_sigmoid), scale, _ptr(self._slate), _ptr(self.partials),
+                                       self.grid, _stream()), "ltr_fused_step")
             if self.kernel_events is not None:
                 self.kernel_events[1].record()
             check(h.ltr_mlp_reduce_grads(self.net, _ptr(self.partials), self.grid, _ptr(self.flat_grad), _stream()),

@@ -103,7 +103,10 @@ def test_double_golden(dev):
 
 
 # ------------------------------------------------------------------------------------- oracle, fresh inputs
-def _oracle_step(kind, sd, x, y, loss, k1=None, k2=None, dtype=torch.float64):
+LAMBDA_KW = dict(weighing_scheme="ndcgLoss2PP_scheme", k=None, sigma=1.0, mu=10.0, reduction="sum", reduction_log="binary")
+
+
+def _oracle_step(kind, sd, x, y, loss, k1=None, k2=None, dtype=torch.float64, lambda_kw=None):
     """CPU oracle (fp64 by default): loss and parameter gradients by autograd over the restatement."""
     p = {k: v.to(dtype).clone().requires_grad_(True) for k, v in sd.items()}
     xd = x.to(dtype)
@@ -112,7 +115,12 @@ def _oracle_step(kind, sd, x, y, loss, k1=None, k2=None, dtype=torch.float64):
     else:
         s = O.double_layer_forward(xd, p, None if k1 is None else k1.to(dtype), None if k2 is None else k2.to(dtype))
     s = s.squeeze(-1)
-    l = O.approx_ndcg(s, y.to(dtype)) if loss == "approxNDCG" else O.listnet(y.to(dtype), s)
+    if loss == "approxNDCG":
+        l = O.approx_ndcg(s, y.to(dtype))
+    elif loss == "listnet":
+        l = O.listnet(y.to(dtype), s)
+    else:
+        l = O.lambda_loss(s, y.to(dtype), **(lambda_kw or LAMBDA_KW))
     l.backward()
     return l.detach().numpy(), {k: v.grad.numpy() for k, v in p.items()}, s.detach().numpy()
 
@@ -153,6 +161,34 @@ def test_fused_step_vs_oracle(kind, S, B, loss, dev):
     # p.grad aliases the flat buffer, in parameters() order
     flat = torch.cat([p.grad.reshape(-1) for p in net.parameters()])
     assert torch.equal(flat, ranker.flat_grad)
+
+
+@pytest.mark.parametrize("kind", ["triple", "double_eval"])
+@pytest.mark.parametrize("S", [32, 128])
+@pytest.mark.parametrize("scheme,k,sigma,log", [("ndcgLoss2PP_scheme", None, 1.0, "binary"), ("ndcgLoss1_scheme", 10, 2.0, "natural"),
+                                               (None, None, 1.0, "binary"), ("lamdbaRank_scheme", 5, 1.0, "binary"),
+                                               ("rankNetWeightedByGTDiffPowed_scheme", None, 0.5, "natural")])
+def test_fused_lambda_vs_oracle(kind, S, scheme, k, sigma, log, dev):
+    """Fused scorer + lambdaLoss (the loss main_batch_execution.py:135 trains with) vs the fp64 oracle."""
+    from ltr_mi355x.scorer import FusedRanker
+    net, sd = _make(kind.split("_")[0], dev, 13)
+    net.eval()
+    B = 7
+    gen = torch.Generator().manual_seed(77 + S)
+    x = torch.randn(B, S, 136, generator=gen)
+    y = torch.randint(0, 5, (B, S), generator=gen).float()
+    y[2, S - 5:] = -1.0                                       # a padded tail
+    kw = dict(weighing_scheme=scheme, k=k, sigma=sigma, mu=10.0, reduction="sum", reduction_log=log)
+    rl, rg, _ = _oracle_step(kind.split("_")[0], sd, x, y, "lambdaLoss", lambda_kw=kw)
+    _, rg32, _ = _oracle_step(kind.split("_")[0], sd, x, y, "lambdaLoss", dtype=torch.float32, lambda_kw=kw)
+    ranker = FusedRanker(net, loss="lambdaLoss", weighing_scheme=scheme, k=k, sigma=sigma, reduction_log=log)
+    out = ranker.step(x.to(dev), y.to(dev))
+    assert relerr(out.cpu().numpy(), rl) < TOL
+    assert_grads(_grads(net), rg, ref32=rg32)
+    with pytest.raises(NotImplementedError):
+        FusedRanker(net, loss="lambdaLoss", reduction="mean")
+    with pytest.raises(ValueError, match="Reduction logarithm base"):
+        FusedRanker(net, loss="lambdaLoss", reduction_log="decimal")
 
 
 @pytest.mark.parametrize("kind", ["triple", "double"])
