@@ -156,6 +156,11 @@ int ltr_fused_step(int net, int loss_kind, const float *X, const float *labels, 
                    float pad, int apply_sigmoid, float grad_scale, float *slate_loss, float *partials, int grid,
                    void *stream);
 
+/* Diagnostics: in a build compiled with -DLTR_STAMPS the pipeline kernels write s_memtime stamps at their phase
+ * boundaries for workgroup-local tile `tile` to buf[grid][8][16] (uint64); returns 1 in such a build, 0 otherwise
+ * (the stamps are then compiled out).  buf = NULL disables. */
+int ltr_debug_set_stamps(void *buf, int tile);
+
 /* The same fused pass with lambdaLoss (losses/lambdaL.py:67-93; the loss main_batch_execution.py:135 trains
  * with: weighing_scheme="ndcgLoss2PP_scheme").  scheme/k/sigma/mu/eps/log_base as in ltr_lambda_fwd_bwd;
  * slate_loss[b] = -sum of the kept pair terms, slate_count[b] (may be NULL) = kept pairs.  reduction="sum":

@@ -100,6 +100,8 @@ struct PipeArgs {
     float alpha, eps, pad, gscale;
     int apply_sigmoid;
     int n_super;
+    unsigned long long *stamps;   // diagnostic build (-DLTR_STAMPS) only: [grid][8 waves][16] s_memtime values
+    int stamp_tile;               // ... of this workgroup-local tile iteration
     int debug_skip;          // timing experiments only (env LTR_DEBUG_SKIP): 1 loss, 2 dW GEMMs, 4 dh1, 8 fc2, 16 fc1
 };
 
@@ -323,6 +325,14 @@ __device__ __forceinline__ void dw_store(int w, const f32x4 (&acc)[TW], float *d
     }
 }
 
+#ifdef LTR_STAMPS
+#define LTR_STAMP(k)                                                                                          \
+    if (a.stamps && lane == 0 && (st - (int)blockIdx.x) / (int)gridDim.x == a.stamp_tile)                      \
+        a.stamps[((size_t)blockIdx.x * kWaves + w) * 16 + (k)] = __builtin_readcyclecounter();
+#else
+#define LTR_STAMP(k)
+#endif
+
 // LOSS (MODE_FUSED only): 0 approxNDCG, 1 ListNet, 2 LambdaLoss -- a template parameter so that each fused
 // kernel carries only its own loss code (sharing one kernel cost the approxNDCG path 2 % in registers/code).
 // This wave's 16 documents of a super-tile: kXV4 float4 per lane, zeros past the end of the batch.
@@ -340,6 +350,31 @@ __device__ __forceinline__ void load_x_tile(f32x4 (&xr)[kXV4<N>()], const PipeAr
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
         if (e < V4 && row0 + e / V4_PER_ROW < a.n_docs) v = src[e];
         xr[m] = v;
+    }
+}
+
+#ifndef LTR_XDMA
+#define LTR_XDMA 1
+#endif
+// X: HBM/L2 -> LDS by LDS-DMA (global_load_lds, 16 B per lane, no VGPRs, no address math): one wave-instruction
+// per document row, lanes 0..F/4-1 active, destination = row base + lane*16 (rows keep their padded LD stride;
+// the pad columns -- ones feature + zeros -- are constant and written once per kernel).  Rows past the end of
+// the batch are zero-filled.  Issued and waited for at the top of a tile, with no other vector-memory load in
+// flight: while an LDS-DMA is pending hipcc turns every vmcnt wait into vmcnt(0), so overlapping it with the
+// weight-fragment ring or the dW GEMMs costs more than it hides (measured, profiles/r01_variant_ab.json).
+template <class N>
+__device__ __forceinline__ void dma_x_rows(const PipeArgs &a, float *Xs, long long row0, int w, int lane) {
+    typedef __attribute__((address_space(1))) const void *gptr_t;
+    typedef __attribute__((address_space(3))) void *lptr_t;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        float *dst = Xs + (16 * w + r) * N::LD;                 // wave-uniform
+        if (row0 + r < a.n_docs) {                               // wave-uniform
+            if (lane < N::F / 4)
+                __builtin_amdgcn_global_load_lds((gptr_t)(a.X + (row0 + r) * N::F + 4 * lane), (lptr_t)dst, 16, 0, 0);
+        } else if (lane < N::F / 4) {
+            *reinterpret_cast<f32x4 *>(dst + 4 * lane) = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
     }
 }
 
@@ -387,12 +422,26 @@ __global__ void __launch_bounds__(kThreads, 2) slate_pipeline_kernel(const PipeA
     const int crow = 16 * (w & 3) + d;                     // ... and its row inside the chunk
 
     constexpr bool XPREF = x_reg_prefetch<N, MODE>();
+    constexpr bool XDMA = LTR_XDMA && !XPREF;
     f32x4 xn[kXV4<N>()];
+    if (XDMA) {   // pad columns of the X tile (ones feature at column F, zeros up to LD): constant, written once
+        constexpr int PADV4 = (LD - N::F) / 4;
+        for (int e = tid; e < kTileDocs * PADV4; e += kThreads) {
+            const int r = e / PADV4, c4 = e - r * PADV4;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (c4 == 0) v[0] = 1.f;
+            *reinterpret_cast<f32x4 *>(Xs + r * LD + N::F + 4 * c4) = v;
+        }
+    }
     for (int st = blockIdx.x; st < a.n_super; st += gridDim.x) {
         const long long doc_base = (long long)st * kTileDocs;
+        LTR_STAMP(0)
         __syncthreads();   // previous super-tile done with Xs / sc / dsc
         // ---- X: HBM -> LDS, coalesced 16 B per lane; the wave's 16 documents are contiguous in memory.
-        {
+        if (XDMA) {
+            dma_x_rows<N>(a, Xs, doc_base + 16 * w, w, lane);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        } else {
             // register-prefetch kernels: only the first tile is loaded here, later ones arrive ahead of time
             if (!XPREF || st == (int)blockIdx.x) load_x_tile<N>(xn, a, doc_base + 16 * w, lane);
             constexpr int V4_PER_ROW = N::F / 4;
@@ -426,6 +475,7 @@ __global__ void __launch_bounds__(kThreads, 2) slate_pipeline_kernel(const PipeA
         }
         __syncthreads();
 
+        LTR_STAMP(1)
         const long long gdoc = doc_base + my_row;
         // forward-only kernels never reach the backward's prefetch point: fetch the next X slice here, it lands
         // during fc1/fc2 (xn was copied to LDS above)
@@ -449,6 +499,7 @@ __global__ void __launch_bounds__(kThreads, 2) slate_pipeline_kernel(const PipeA
             constexpr int Tn = N::H1 / 16, p = N::H1 % 16;
             h1[Tn][p % 4] = (q == p / 4) ? 1.f : h1[Tn][p % 4];
         }
+        LTR_STAMP(2)
         // ---- fc2
         f32x4 h2[N::NT2];
         if (!(a.debug_skip & 8)) gemm_wx<N::NT2, N::H1T>(wrsrc, N::W2F_OFF * 4, lane_off, h1, h2);
@@ -456,6 +507,7 @@ __global__ void __launch_bounds__(kThreads, 2) slate_pipeline_kernel(const PipeA
 #pragma unroll
             for (int To = 0; To < N::NT2; ++To) h2[To] = h1[To];
         activate<N::A2, N::H2, N::NT2>(h2, q, a, 1, a.keep2, gdoc);
+        LTR_STAMP(3)
         // ---- fc3: s = w3 . h2 + b3, reduced over the 4 q-lanes of each document
         {
             float p0 = 0.f;
@@ -474,6 +526,7 @@ __global__ void __launch_bounds__(kThreads, 2) slate_pipeline_kernel(const PipeA
             if (tid < kTileDocs && doc_base + tid < a.n_docs) a.scores_out[doc_base + tid] = sc[tid];
             continue;
         }
+        LTR_STAMP(4)
         // ---- listwise loss on the LDS-resident scores (fused) -> dsc
         if (MODE == MODE_FUSED && (a.debug_skip & 1)) {
             __syncthreads();
@@ -514,6 +567,7 @@ __global__ void __launch_bounds__(kThreads, 2) slate_pipeline_kernel(const PipeA
         }
         __syncthreads();
 
+        LTR_STAMP(5)
         // ---- pull the NEXT super-tile of X into L2 while this one is in its backward (one dword per 128-B line
         //      per lane; the value is only kept alive until the end of the iteration so the load is waited for)
         float pf = 0.f;
@@ -548,6 +602,7 @@ __global__ void __launch_bounds__(kThreads, 2) slate_pipeline_kernel(const PipeA
             }
         }
         // h2 now holds dz2.
+        LTR_STAMP(6)
         // ---- dW2 += dz2^T [h1 | 1] over the two 64-document chunks (tiles of waves 0-3, then waves 4-7)
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
@@ -564,6 +619,7 @@ __global__ void __launch_bounds__(kThreads, 2) slate_pipeline_kernel(const PipeA
             if (!(a.debug_skip & 2))
                 dw_chunk<N::TW2, N::NT2, N::H1T, N::BH2, LD>(w, accW2, Ds + q * LD + d, Hs + q * LD + d);
         }
+        LTR_STAMP(7)
         // ---- dh1^T = W2^T dz2^T  (A = packed W2^T fragments, B = dz2 registers), then
         //      dz1 = dh1 * act1'(h1), features >= H1 (incl. the ones feature) zeroed
         f32x4 dz1[N::NT1];
@@ -580,6 +636,7 @@ __global__ void __launch_bounds__(kThreads, 2) slate_pipeline_kernel(const PipeA
                 if (16 * To + 16 > N::H1) v = (16 * To + 4 * q + r < N::H1) ? v : 0.f;   // last tile only
                 dz1[To][r] = v;
             }
+        LTR_STAMP(8)
         // next super-tile's X slice -> registers now (h1/h2 are dead); it lands during the dW1 MFMAs below
         if (MODE != MODE_FWD && XPREF && st + (int)gridDim.x < a.n_super)
             load_x_tile<N>(xn, a, (long long)(st + gridDim.x) * kTileDocs + 16 * w, lane);
@@ -596,6 +653,7 @@ __global__ void __launch_bounds__(kThreads, 2) slate_pipeline_kernel(const PipeA
             if (!(a.debug_skip & 2))
                 dw_chunk<N::TW1, N::NT1, N::XT, N::BH1, LD>(w, accW1, Ds + q * LD + d, Xs + (64 * c + q) * LD + d);
         }
+        LTR_STAMP(9)
         asm volatile("" ::"v"(pf));   // keep the prefetch load alive (and waited for) until here
     }
 
@@ -767,6 +825,19 @@ int ltr_mlp_pack(int net, const float *W1, const float *b1, const float *W2, con
     return status();
 }
 
+// diagnostic builds (-DLTR_STAMPS): where the phase stamps of the next launches go (NULL: none)
+static unsigned long long *g_stamps = nullptr;
+static int g_stamp_tile = 0;
+int ltr_debug_set_stamps(void *buf, int tile) {
+    g_stamps = static_cast<unsigned long long *>(buf);
+    g_stamp_tile = tile;
+#ifdef LTR_STAMPS
+    return 1;
+#else
+    return 0;
+#endif
+}
+
 static int fill_common(PipeArgs &a, int net, const float *X, int64_t n_docs, const float *packed, int dropout,
                        uint64_t seed, const uint8_t *keep1, const uint8_t *keep2) {
     if (!X || !packed) return LTR_ERR_NULL;
@@ -784,6 +855,8 @@ static int fill_common(PipeArgs &a, int net, const float *X, int64_t n_docs, con
     a.n_super = (int)((n_docs + kTileDocs - 1) / kTileDocs);
     static const int dbg = getenv("LTR_DEBUG_SKIP") ? atoi(getenv("LTR_DEBUG_SKIP")) : 0;
     a.debug_skip = dbg;
+    a.stamps = g_stamps;
+    a.stamp_tile = g_stamp_tile;
     return LTR_OK;
 }
 

@@ -11,6 +11,7 @@ PROTOTYPES = {
     "ltr_mlp_reduce_grads": (c_int, [c_int, P, c_int, P, P]),
     "ltr_fused_step": (c_int, [c_int, c_int, P, P, c_int, c_int, P, c_int, c_uint64, P, P, c_float, c_float, c_float,
                                c_int, c_float, P, P, c_int, P]),
+    "ltr_debug_set_stamps": (c_int, [P, c_int]),
     "ltr_fused_step_lambda": (c_int, [c_int, P, P, c_int, c_int, P, c_int, c_uint64, P, P, c_int, c_int, c_float, c_float,
                                       c_float, c_float, c_int, c_float, P, P, P, c_int, P]),
 }
