@@ -542,9 +542,10 @@ __global__ void __launch_bounds__(kThreads, 2) slate_pipeline_kernel(const PipeA
             if (LOSS == 0) {
                 auto st_ds = [&](int i, float v) { dsc[so + i] = v; };
                 // group = 4 S -> 4 column groups per row: block length S / 4, known at compile time per branch
+                auto stamp_fn = [&](int k) { LTR_STAMP(k) };
                 if (a.S == 128)
                     loss = approx_ndcg_slate<32>(g, sc + so, yl + so, gn + so, gg + so, uu + so, mk + so, a.alpha,
-                                                 a.eps, a.gscale, true, st_ds);
+                                                 a.eps, a.gscale, true, st_ds, stamp_fn);
                 else if (a.S == 64)
                     loss = approx_ndcg_slate<16>(g, sc + so, yl + so, gn + so, gg + so, uu + so, mk + so, a.alpha,
                                                  a.eps, a.gscale, true, st_ds);

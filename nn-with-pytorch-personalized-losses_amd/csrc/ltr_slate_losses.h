@@ -79,10 +79,14 @@ __device__ __forceinline__ void group_minmax(const SlateGroup &g, float &lo, flo
 
 // JB > 0: the caller guarantees every column block is exactly JB documents (S = JB * CG, JB % 4 == 0), so the
 // pair sweeps have compile-time trip counts and unroll fully; JB == 0: general shapes.
-template <int JB = 0, class Store>
+struct NoStamp {
+    __device__ __forceinline__ void operator()(int) const {}
+};
+
+template <int JB = 0, class Store, class Stamp = NoStamp>
 __device__ __forceinline__ float approx_ndcg_slate(const SlateGroup &g, float *sc, float *yl, const float *gn,
                                                    float *gg, float *uu, float *mk, float alpha, float eps,
-                                                   float gscale, bool want_grad, Store store) {
+                                                   float gscale, bool want_grad, Store store, Stamp stamp = Stamp()) {
     const int s_al = (g.S + 3) & ~3;
     // contiguous column block of this column group, multiple of 4
     const int jb = JB > 0 ? JB : ((((g.S + g.CG - 1) / g.CG) + 3) & ~3);
@@ -99,6 +103,7 @@ __device__ __forceinline__ float approx_ndcg_slate(const SlateGroup &g, float *s
         }
     }
     group_minmax(g, lo, hi);
+    stamp(10);
     const bool fast = (hi - lo) <= 160.f;   // false for NaN too
     const float mid = 0.5f * (hi + lo);
     for (int j = g.t; j < s_al; j += g.group) {
@@ -112,6 +117,7 @@ __device__ __forceinline__ float approx_ndcg_slate(const SlateGroup &g, float *s
         gg[j] = 0.f;
     }
     __syncthreads();
+    stamp(11);
 
     // One sweep per row: label rank by counting (ideal DCG term, approxNDCG.py:28,43) and the soft rank
     // pos_i = 1 + sum_{j != i, both valid} max(sigmoid(-alpha (s_i - s_j)), eps)            (:47-49)
@@ -168,7 +174,9 @@ __device__ __forceinline__ float approx_ndcg_slate(const SlateGroup &g, float *s
             gg[i] = gain / (L * L * (1.f + pos) * LTR_LN2);      // d(-sum gain/L)/d pos_i, not yet / maxDCG
         }
     }
+    stamp(12);
     group_sum2(g, idcg_acc, loss_acc);     // its barriers also publish gg
+    stamp(13);
     const float inv_idcg = 1.f / fmaxf(idcg_acc, eps);          // maxDCG clamp (:43)
     const float total = loss_acc * inv_idcg;
     if (!want_grad) return -total;
@@ -216,6 +224,7 @@ __device__ __forceinline__ float approx_ndcg_slate(const SlateGroup &g, float *s
         const float tot = row_reduce(g, a);
         if (row && g.cg == 0) store(k, vk ? kscale * tot : 0.f);
     }
+    stamp(14);
     return -total;
 }
 

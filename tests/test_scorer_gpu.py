@@ -213,6 +213,25 @@ def test_module_path_any_shape(kind, n_docs, dev):
                  ref32={k: v.grad.numpy() for k, v in p32.items()})
 
 
+@pytest.mark.parametrize("kind", ["triple", "double"])
+def test_slate512_lambda_through_modules(kind, dev):
+    """BASELINE config 3 shape: lambdaLoss (ndcgLoss2PP) at slate 512 through the nn.Module path --
+    forward launch, loss launch, backward launch (slates > 128 are not fused) -- vs the fp64 oracle."""
+    from losses.lambdaL import lambdaLoss
+    net, sd = _make(kind, dev, 17)
+    net.eval()
+    B, S = 3, 512
+    gen = torch.Generator().manual_seed(512)
+    x = torch.randn(B, S, 136, generator=gen)
+    y = torch.randint(0, 5, (B, S), generator=gen).float()
+    loss = lambdaLoss(torch.squeeze(net(x.to(dev), None, None)), y.to(dev), weighing_scheme="ndcgLoss2PP_scheme")
+    loss.backward()
+    rl, rg, _ = _oracle_step(kind, sd, x, y, "lambdaLoss")
+    _, rg32, _ = _oracle_step(kind, sd, x, y, "lambdaLoss", dtype=torch.float32)
+    assert relerr(loss.detach().cpu().numpy(), rl) < TOL
+    assert_grads(_grads(net), rg, ref32=rg32)
+
+
 def test_dropout_stream(dev):
     """The counter-based dropout stream: ~Bernoulli(0.5), layer/seed dependent, and the forward under it
     equals the oracle forward under the exported masks; fused == unfused for the same seed."""

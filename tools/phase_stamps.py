@@ -35,6 +35,10 @@ for name, cls in (("double", DoubleLayerNet), ("triple", TripleLayerNet)):
     d = t[:, :, 1:10] - t[:, :, 0:9]
     med = d.reshape(-1, 9).median(0).values
     tot = float((t[:, :, 9] - t[:, :, 0]).reshape(-1).median())
-    rec = {"net": name, "total_cycles": tot, "phases": {n: round(float(v)) for n, v in zip(NAMES, med)},
+    lo = t[:, :, [4, 10, 11, 12, 13, 14, 5]]
+    ld = (lo[:, :, 1:] - lo[:, :, :-1]).reshape(-1, 6).median(0).values
+    loss_names = ["entry barrier+range scan+minmax", "init u/mask + barrier", "rank+pos sweep", "sum2 (2 barriers)",
+                  "grad sweep", "store + exit barrier"]
+    rec = {"net": name, "loss_detail": {n: round(float(v)) for n, v in zip(loss_names, ld)}, "total_cycles": tot, "phases": {n: round(float(v)) for n, v in zip(NAMES, med)},
            "share_pct": {n: round(100 * float(v) / tot, 1) for n, v in zip(NAMES, med)}}
     print(json.dumps(rec), flush=True)
