@@ -126,11 +126,17 @@ def main():
     if world != a.gpus:
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {a.gpus}")
     import torch.distributed as dist
-    dev = torch.device("cuda", local_rank)
+    # one process per GPU.  (Rehearsal on a box with fewer GPUs than ranks: ranks share cards and
+    # LTR_DIST_BACKEND=gloo stands in for RCCL, which refuses two ranks on one device.)
+    backend = os.environ.get("LTR_DIST_BACKEND", "nccl")
+    dev = torch.device("cuda", local_rank % torch.cuda.device_count())
     torch.cuda.set_device(dev)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     from architeture.doubleLayer import DoubleLayerNet
     from architeture.tripleLayer import TripleLayerNet
