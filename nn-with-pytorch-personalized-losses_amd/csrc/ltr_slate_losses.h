@@ -93,30 +93,31 @@ __device__ __forceinline__ float approx_ndcg_slate(const SlateGroup &g, float *s
     const int j0 = g.cg * jb;
     const int j1 = JB > 0 ? j0 + JB : min(j0 + jb, s_al);
 
-    // score range over the real documents -> fast/slow path (slate-uniform)
-    float lo = INFINITY, hi = -INFINITY;
-    for (int j = g.t; j < g.S; j += g.group) {
-        if (gn[j] >= 0.f) {
-            const float x = alpha * sc[j];
-            lo = fminf(lo, x);
-            hi = fmaxf(hi, x);
-        }
-    }
-    group_minmax(g, lo, hi);
-    stamp(10);
-    const bool fast = (hi - lo) <= 160.f;   // false for NaN too
-    const float mid = 0.5f * (hi + lo);
+    // Per-document exponentials relative to the first document's score.  The fast path is valid while every
+    // |alpha (s_k - s_0)| <= 69 (u in [1e-30, 1e30]: sums and ratios stay in fp32 range); one flag per wave,
+    // combined behind the SAME barrier that publishes uu / mk / gg, decides fast vs slow for the whole slate.
+    const float sref = alpha * sc[0];
+    bool bad = false;
     for (int j = g.t; j < s_al; j += g.group) {
         const bool real = j < g.S && gn[j] >= 0.f;
+        const float x = real ? alpha * sc[j] - sref : 0.f;
+        bad = bad || !(fabsf(x) <= 69.f);          // NaN scores take the slow path too
         mk[j] = real ? 1.f : 0.f;
-        uu[j] = (real && fast) ? expf(alpha * sc[j] - mid) : 1.f;
+        uu[j] = real ? expf(x) : 1.f;
         if (j >= g.S) {
             sc[j] = 0.f;
             yl[j] = -INFINITY;
         }
         gg[j] = 0.f;
     }
+    if ((threadIdx.x & (LTR_WAVE - 1)) == 0) g.part[g.wig] = 0.f;
+    __builtin_amdgcn_wave_barrier();
+    if (bad) g.part[g.wig] = 1.f;                   // benign same-value race inside one wave
     __syncthreads();
+    stamp(10);
+    float nbad = 0.f;
+    for (int w = 0; w < g.nw; ++w) nbad += g.part[w];
+    const bool fast = nbad == 0.f;
     stamp(11);
 
     // One sweep per row: label rank by counting (ideal DCG term, approxNDCG.py:28,43) and the soft rank
@@ -175,12 +176,24 @@ __device__ __forceinline__ float approx_ndcg_slate(const SlateGroup &g, float *s
         }
     }
     stamp(12);
-    group_sum2(g, idcg_acc, loss_acc);     // its barriers also publish gg
+    // wave partials -> LDS, ONE barrier (it also publishes gg), every thread adds the waves in fixed order
+    idcg_acc = wave_allsum(idcg_acc);
+    loss_acc = wave_allsum(loss_acc);
+    if ((threadIdx.x & (LTR_WAVE - 1)) == 0) {
+        g.red[2 * g.wig] = idcg_acc;
+        g.red[2 * g.wig + 1] = loss_acc;
+    }
+    __syncthreads();
+    idcg_acc = 0.f;
+    loss_acc = 0.f;
+    for (int w = 0; w < g.nw; ++w) {
+        idcg_acc += g.red[2 * w];
+        loss_acc += g.red[2 * w + 1];
+    }
     stamp(13);
     const float inv_idcg = 1.f / fmaxf(idcg_acc, eps);          // maxDCG clamp (:43)
     const float total = loss_acc * inv_idcg;
     if (!want_grad) return -total;
-    if (g.nw == 1) __syncthreads();
 
     // d loss / d s_k = alpha * sum_j t_kj (g_j [c_jk >= eps] - g_k [c_kj >= eps]),  t = c_kj c_jk
     const float kscale = alpha * gscale * inv_idcg;
