@@ -116,6 +116,8 @@ def main():
     ap.add_argument("--slate", type=int, default=128)
     ap.add_argument("--batch", type=int, default=25_000, help="slates per GPU per step")
     ap.add_argument("--net", choices=["double", "triple"], default="double")
+    ap.add_argument("--loss", choices=["approxNDCG", "listnet", "lambdaLoss"], default="approxNDCG",
+                    help="headline metric is approxNDCG; lambdaLoss uses ndcgLoss2PP_scheme (main_batch_execution.py:135)")
     ap.add_argument("--eval-mode", action="store_true", help="no dropout (default: training mode, like the reference loop)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     a = ap.parse_args()
@@ -149,7 +151,7 @@ def main():
     sync_parameters(net)
     Q, S, B = a.queries, a.slate, min(a.batch, a.queries)
     X, y = synth(Q, S, dev, 2020 + rank)
-    ranker = FusedRanker(net, loss="approxNDCG")
+    ranker = FusedRanker(net, loss=a.loss, **({"weighing_scheme": "ndcgLoss2PP_scheme"} if a.loss == "lambdaLoss" else {}))
     ranker.seed_salt = rank
     opt = torch.optim.Adam(net.parameters(), lr=1e-3, fused=True)
     trainer = QueryShardedTrainer(ranker, opt)
@@ -189,20 +191,23 @@ def main():
         ach_tf = fl_slate * B / (kern_ms * 1e-3) / 1e12
         ach_gb = by_slate * B / (kern_ms * 1e-3) / 1e9
         out = {
-            "metric": "slates/sec fwd+bwd approxNDCG slate=128 feat=136",
+            "metric": f"slates/sec fwd+bwd {a.loss} slate={S} feat={F}",
             "value": round(slates_per_s, 1), "unit": "slates/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(dt / a.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"approxNDCG + {a.net}LayerNet ({'136-136-136-1' if a.net == 'double' else '136-64-32-1'}) "
+            "config": {"workload": f"{a.loss} + {a.net}LayerNet ({'136-136-136-1' if a.net == 'double' else '136-64-32-1'}) "
                                    f"{'train-mode dropout' if net.training and a.net == 'double' else 'no dropout'}, "
                                    f"{Q} queries x slate {S} x {F} feat fp32 per GPU resident in HBM, "
-                                   f"{B} slates per GPU per step, fused fwd+loss+bwd + grad all-reduce + Adam",
+                                   f"{B} slates per GPU per step, "
+                                   f"{'one fused launch (fwd+loss+bwd)' if S in (32, 64, 128) else 'forward launch + loss kernel + backward launch'}"
+                                   " + grad all-reduce + Adam",
                        "queries_per_gpu": Q, "slate": S, "features": F, "batch_per_gpu": B, "net": a.net,
                        "parallelism": f"query-sharded dp{world}", "final_loss": round(final_loss, 6)},
             "roofline": {"bound": "mfma", "achieved": round(ach_tf, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(ach_tf / PEAK_F32_MFMA_TFLOPS, 4),
                          "traffic": pmc_traffic_per_launch(a.net, B) if S == 128 else None,
-                         "kernel": "slate_pipeline_kernel<MODE_FUSED>", "kernel_ms": round(kern_ms, 4),
+                         "kernel": "slate_pipeline_kernel<MODE_FUSED>" if S in (32, 64, 128) else "slate_pipeline_kernel<MODE_BWD>",
+                         "kernel_ms": round(kern_ms, 4),
                          "flops_per_slate": fl_slate, "bytes_per_slate": by_slate,
                          "hbm_achieved_GBps": round(ach_gb, 1), "hbm_frac_of_8TBps": round(ach_gb / PEAK_HBM_GBPS, 4),
                          "hbm_frac_of_measured_copy": round(ach_gb / PEAK_HBM_MEASURED_GBPS, 4)},

@@ -181,7 +181,8 @@ lambda_pairs_fwd_kernel(const float *__restrict__ scores, const float *__restric
         const float Gi = fmaxf(L.gn[i], 0.f), Gj = fmaxf(L.gn[j], 0.f);
         const float yci = fmaxf(L.yl[i], 0.f), ycj = fmaxf(L.yl[j], 0.f);
         float ell, dl;
-        lambda_pair_term(P, lambda_weight<SCH>(L, P, i, j, Gi, Gj, yci, ycj), u, um, ell, dl);
+        lambda_pair_term(P, lambda_weight<SCH>(P, L.delta, L.rk[i], L.rk[j], L.invd[i], L.invd[j], L.w1[i], Gi, Gj, yci, ycj),
+                         u, um, ell, dl);
         losses[moff + e] = ell;
         if (keep) {
             const bool ok = !pi && !pj && (P.k <= 0 || (ri < P.k && rj < P.k)) && (SCH == 1 || L.yl[i] > L.yl[j]);
@@ -227,8 +228,10 @@ lambda_pairs_bwd_kernel(const float *__restrict__ scores, const float *__restric
                 sigmoid_pair(P.sigma * draw, u, um);
                 const float ycj = fmaxf(L.yl[j], 0.f);
                 float ell, dl_ij, dl_ji;
-                lambda_pair_term(P, lambda_weight<SCH>(L, P, i, j, Gi, Gj, yci, ycj), u, um, ell, dl_ij);
-                lambda_pair_term(P, lambda_weight<SCH>(L, P, j, i, Gj, Gi, ycj, yci), um, u, ell, dl_ji);
+                lambda_pair_term(P, lambda_weight<SCH>(P, L.delta, ri, rj, L.invd[i], L.invd[j], L.w1[i], Gi, Gj, yci, ycj),
+                                 u, um, ell, dl_ij);
+                lambda_pair_term(P, lambda_weight<SCH>(P, L.delta, rj, ri, L.invd[j], L.invd[i], L.w1[j], Gj, Gi, ycj, yci),
+                                 um, u, ell, dl_ji);
                 gr += G[(size_t)ri * S + rj] * dl_ij - G[(size_t)rj * S + ri] * dl_ji;
             }
         }

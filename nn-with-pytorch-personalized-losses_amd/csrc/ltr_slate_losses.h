@@ -311,60 +311,102 @@ struct LambdaLds {
     int *rk;       // [S] 0-based predicted rank of document i
 };
 
-// Rank by counting on the scores (padded documents rank last), G, and the per-document weight inputs.
+// Rank by counting on labels (ideal DCG) and on scores (predicted rank; padded documents rank last), G, and the
+// per-document weight inputs -- ONE sweep over contiguous column blocks with 16-byte LDS broadcast reads.
+// All LambdaLds arrays have s_al = (S+3)&~3 entries; on entry sc/yl/gn hold [0,S).  L.delta doubles as scratch
+// for the masked scores during the sweep and receives the delta table afterwards.
 __device__ __forceinline__ void lambda_prepare(const SlateGroup &g, const LambdaLds &L, const LambdaParams &P) {
-    const float idcg = ideal_dcg(g, L.yl, L.gn, P.eps, P.k);
+    const int s_al = (g.S + 3) & ~3;
+    const int jb = (((g.S + g.CG - 1) / g.CG) + 3) & ~3;
+    const int j0 = g.cg * jb;
+    const int j1 = min(j0 + jb, s_al);
+    float *sm = L.delta;
+    for (int j = g.t; j < s_al; j += g.group) {
+        const bool real = j < g.S && L.gn[j] >= 0.f;
+        sm[j] = real ? L.sc[j] : -INFINITY;
+        if (j >= g.S) {
+            L.sc[j] = 0.f;
+            L.yl[j] = -INFINITY;
+            L.gn[j] = -1.f;
+            L.invd[j] = 0.f;
+            L.w1[j] = 0.f;
+            L.rk[j] = g.S;
+        }
+    }
     __syncthreads();
-    for (int j = g.t; j < g.S; j += g.group) {
-        const float v = L.gn[j];
-        L.gn[j] = v < 0.f ? -1.f : v / idcg;
+    float idcg_acc = 0.f;
+    for (int i0 = 0; i0 < g.S; i0 += g.sp) {
+        const int i = i0 + g.ri;
+        const bool row = i < g.S;
+        float cl = 0.f, cs = 0.f;
+        if (row) {
+            const float yi = L.yl[i], si = sm[i];
+            float a0 = 0.f, a1 = 0.f, b0 = 0.f, b1 = 0.f;
+#pragma unroll 2
+            for (int j = j0; j < j1; j += 4) {
+                const lds_f4 y = *reinterpret_cast<const lds_f4 *>(L.yl + j);
+                const lds_f4 v = *reinterpret_cast<const lds_f4 *>(sm + j);
+                a0 += ((y[0] > yi) || (y[0] == yi && j + 0 < i)) ? 1.f : 0.f;
+                a1 += ((y[1] > yi) || (y[1] == yi && j + 1 < i)) ? 1.f : 0.f;
+                a0 += ((y[2] > yi) || (y[2] == yi && j + 2 < i)) ? 1.f : 0.f;
+                a1 += ((y[3] > yi) || (y[3] == yi && j + 3 < i)) ? 1.f : 0.f;
+                b0 += ((v[0] > si) || (v[0] == si && j + 0 < i)) ? 1.f : 0.f;
+                b1 += ((v[1] > si) || (v[1] == si && j + 1 < i)) ? 1.f : 0.f;
+                b0 += ((v[2] > si) || (v[2] == si && j + 2 < i)) ? 1.f : 0.f;
+                b1 += ((v[3] > si) || (v[3] == si && j + 3 < i)) ? 1.f : 0.f;
+            }
+            cl = a0 + a1;
+            cs = b0 + b1;
+        }
+        const float rl = row_reduce(g, cl);
+        const float rs = row_reduce(g, cs);
+        if (row && g.cg == 0) {
+            const float gi = L.gn[i];
+            if (gi > 0.f && (P.k <= 0 || rl < (float)P.k)) idcg_acc += gi / log2f(2.f + rl);
+            L.rk[i] = (int)rs;
+            L.invd[i] = 1.f / log2f(2.f + rs);
+        }
+    }
+    idcg_acc = wave_allsum(idcg_acc);
+    if ((threadIdx.x & (LTR_WAVE - 1)) == 0) g.red[g.wig] = idcg_acc;
+    __syncthreads();          // sweep done with sm (= L.delta); rk / invd / wave partials published
+    float idcg = 0.f;
+    for (int w = 0; w < g.nw; ++w) idcg += g.red[w];
+    idcg = fmaxf(idcg, P.eps);
+    for (int j = g.t; j < s_al; j += g.group) {
+        if (j < g.S) {
+            const float v = L.gn[j];
+            const float G = v < 0.f ? -1.f : v / idcg;
+            L.gn[j] = G;
+            L.w1[j] = fmaxf(G, 0.f) / log2f(2.f + (float)L.rk[j]);      // G / D as the reference divides (:97)
+        }
         // D[m] = log2(m + 2);  delta_m = |1/D[m-1] - 1/D[m]|  (lambdaL.py:100-104)
         L.delta[j] = j == 0 ? 0.f : fabsf(1.f / log2f((float)j + 1.f) - 1.f / log2f((float)j + 2.f));
     }
     __syncthreads();
-    for (int i0 = 0; i0 < g.S; i0 += g.sp) {
-        const int i = i0 + g.ri;
-        const bool row = i < g.S;
-        float cnt = 0.f;
-        if (row) {
-            const bool pi = L.gn[i] < 0.f;
-            const float si = pi ? -INFINITY : L.sc[i];
-            for (int j = g.cg; j < g.S; j += g.CG) {
-                const float sj = L.gn[j] < 0.f ? -INFINITY : L.sc[j];
-                cnt += ((sj > si) || (sj == si && j < i)) ? 1.f : 0.f;
-            }
-        }
-        const float r = row_reduce(g, cnt);
-        if (row && g.cg == 0) {
-            const float D = log2f(2.f + r);
-            L.rk[i] = (int)r;
-            L.invd[i] = 1.f / D;
-            L.w1[i] = fmaxf(L.gn[i], 0.f) / D;
-        }
-    }
-    __syncthreads();
 }
 
-// Pair weight w_ij (first element i, second j), lambdaL.py:96-127.  Gi/Gj are 0 for padded documents.
+// Pair weight w for the pair whose FIRST element has (rank r1, 1/D inv1, G/D w1f, gain G1, clamped label y1) and
+// whose second has (r2, inv2, G2, y2), lambdaL.py:96-127.  G is 0 for padded documents.
 // SCH >= 0: scheme fixed at compile time (standalone kernels); SCH < 0: taken from P.scheme at run time
 // (slate-uniform branches; used inside the fused pipeline kernel, which is too large to instantiate 8 times).
 template <int SCH>
-__device__ __forceinline__ float lambda_weight(const LambdaLds &L, const LambdaParams &P, int i, int j, float Gi,
-                                               float Gj, float yci, float ycj) {
+__device__ __forceinline__ float lambda_weight(const LambdaParams &P, const float *delta, int r1, int r2, float inv1,
+                                               float inv2, float w1f, float G1, float G2, float y1, float y2) {
     const int sch = SCH < 0 ? P.scheme : SCH;
     if (sch == 0 || sch == 5) return 1.f;
-    if (sch == 1) return L.w1[i];
-    if (sch == 6) return fabsf(yci - ycj);
-    if (sch == 7) return fabsf(yci * yci - ycj * ycj);
-    const float dG = fabsf(Gi - Gj);
+    if (sch == 1) return w1f;
+    if (sch == 6) return fabsf(y1 - y2);
+    if (sch == 7) return fabsf(y1 * y1 - y2 * y2);
+    const float dG = fabsf(G1 - G2);
     float w = 0.f;
     if (sch == 2 || sch == 4) {
-        int m = L.rk[i] - L.rk[j];
+        int m = r1 - r2;
         m = m < 0 ? -m : m;
-        w = L.delta[m] * dG;
+        w = delta[m] * dG;
         if (sch == 4) w *= P.mu;
     }
-    if (sch == 3 || sch == 4) w += fabsf(L.invd[i] - L.invd[j]) * dG;
+    if (sch == 3 || sch == 4) w += fabsf(inv1 - inv2) * dG;
     return w;
 }
 
@@ -381,10 +423,20 @@ __device__ __forceinline__ void lambda_pair_term(const LambdaParams &P, float w,
 
 // Returns (to every thread) the slate loss -sum_kept ell and writes the kept-pair count to *count_out
 // (every thread gets it); store(i, gscale * dloss/ds_i).
+//
+// Row i sweeps its contiguous column block.  Except for ndcgLoss1 every scheme's weight is symmetric and a pair
+// is kept in exactly ONE orientation (higher label first), so each (i, j) needs one sigmoid pair, one log and
+// one weight: thread i takes the loss term when it owns the first element and the gradient either way.
 template <int SCH, class Store>
 __device__ __forceinline__ float lambda_slate(const SlateGroup &g, const LambdaLds &L, const LambdaParams &P,
                                               float gscale, bool want_grad, float *count_out, Store store) {
     lambda_prepare(g, L, P);
+    const int s_al = (g.S + 3) & ~3;
+    const int jb = (((g.S + g.CG - 1) / g.CG) + 3) & ~3;
+    const int j0 = g.cg * jb;
+    const int j1 = min(j0 + jb, s_al);
+    const bool all_pairs = (SCH < 0 ? P.scheme : SCH) == 1;
+    typedef int lds_i4 __attribute__((ext_vector_type(4)));
     float lossacc = 0.f, cntacc = 0.f;
     for (int i0 = 0; i0 < g.S; i0 += g.sp) {
         const int i = i0 + g.ri;
@@ -393,33 +445,50 @@ __device__ __forceinline__ float lambda_slate(const SlateGroup &g, const LambdaL
         float ls = 0.f, cn = 0.f, gr = 0.f;
         if (vi) {
             const float si = L.sc[i], yi = L.yl[i], Gi = L.gn[i], yci = fmaxf(yi, 0.f);
-            const bool ki = P.k <= 0 || L.rk[i] < P.k;
-            for (int j = g.cg; j < g.S; j += g.CG) {
-                const float Gj = L.gn[j];
-                const bool ok = ki && Gj >= 0.f && (P.k <= 0 || L.rk[j] < P.k);
-                const float yj = L.yl[j];
-                const float draw = si - L.sc[j];
-                const float d = fminf(fmaxf(draw, -1e8f), 1e8f);
-                const bool dlive = fabsf(draw) <= 1e8f;
-                float u, um;
-                sigmoid_pair(P.sigma * d, u, um);
-                const float ycj = fmaxf(yj, 0.f);
-                // pair (i, j): i first.  ndcgLoss1 keeps every valid pair incl. the diagonal (:26-27).
-                const bool all_pairs = (SCH < 0 ? P.scheme : SCH) == 1;
-                const bool caseA = ok && (all_pairs || yi > yj);
-                // pair (j, i): i second (gradient only; its loss term is counted by thread j).
-                const bool caseB = ok && j != i && (all_pairs || yj > yi);
-                if (caseA) {
-                    float ell, dl;
-                    lambda_pair_term(P, lambda_weight<SCH>(L, P, i, j, Gi, fmaxf(Gj, 0.f), yci, ycj), u, um, ell, dl);
-                    ls += ell;
-                    cn += 1.f;
-                    gr -= (dlive && j != i) ? dl : 0.f;
-                }
-                if (caseB) {
-                    float ell, dl;
-                    lambda_pair_term(P, lambda_weight<SCH>(L, P, j, i, fmaxf(Gj, 0.f), Gi, ycj, yci), um, u, ell, dl);
-                    gr += dlive ? dl : 0.f;
+            const float invi = L.invd[i], w1i = L.w1[i];
+            const int ri = L.rk[i];
+            const bool ki = P.k <= 0 || ri < P.k;
+            for (int j4 = j0; j4 < j1; j4 += 4) {
+                const lds_f4 vs = *reinterpret_cast<const lds_f4 *>(L.sc + j4);
+                const lds_f4 vy = *reinterpret_cast<const lds_f4 *>(L.yl + j4);
+                const lds_f4 vg = *reinterpret_cast<const lds_f4 *>(L.gn + j4);
+                const lds_f4 vd = *reinterpret_cast<const lds_f4 *>(L.invd + j4);
+                const lds_f4 vw = *reinterpret_cast<const lds_f4 *>(L.w1 + j4);
+                const lds_i4 vr = *reinterpret_cast<const lds_i4 *>(L.rk + j4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int j = j4 + e;
+                    const float Gj = vg[e], yj = vy[e];
+                    const bool ok = ki && Gj >= 0.f && (P.k <= 0 || vr[e] < P.k);
+                    const float draw = si - vs[e];
+                    const float dcl = fminf(fmaxf(draw, -1e8f), 1e8f);
+                    const bool dlive = fabsf(draw) <= 1e8f;
+                    float u, um;
+                    sigmoid_pair(P.sigma * dcl, u, um);
+                    const float ycj = fmaxf(yj, 0.f), Gjp = fmaxf(Gj, 0.f);
+                    if (!all_pairs) {
+                        const bool hi = yi > yj;                       // i is the first element of the kept pair
+                        const bool kept = ok && yi != yj;
+                        const float w = lambda_weight<SCH>(P, L.delta, ri, vr[e], invi, vd[e], 0.f, Gi, Gjp, yci, ycj);
+                        float ell, dl;
+                        lambda_pair_term(P, w, hi ? u : um, hi ? um : u, ell, dl);
+                        ls += (kept && hi) ? ell : 0.f;
+                        cn += (kept && hi) ? 1.f : 0.f;
+                        gr += (kept && dlive) ? (hi ? -dl : dl) : 0.f;
+                    } else {
+                        // ndcgLoss1 keeps every valid pair incl. the diagonal, in both orientations (:26-27)
+                        float ell, dl;
+                        if (ok) {
+                            lambda_pair_term(P, w1i, u, um, ell, dl);                 // pair (i, j)
+                            ls += ell;
+                            cn += 1.f;
+                            gr -= (dlive && j != i) ? dl : 0.f;
+                        }
+                        if (ok && j != i) {
+                            lambda_pair_term(P, vw[e], um, u, ell, dl);               // pair (j, i): gradient only
+                            gr += dlive ? dl : 0.f;
+                        }
+                    }
                 }
             }
         }

@@ -182,12 +182,10 @@ class FusedRanker:
         self.apply_sigmoid = bool(apply_sigmoid)
         if self.loss_kind == LOSS_LAMBDA:
             from .functional import _lambda_args
-            if reduction == "mean":
-                raise NotImplementedError('fused lambdaLoss supports reduction="sum" (the reference default); '
-                                          'use losses.lambdaL.lambdaLoss for "mean"')
-            if reduction != "sum":
+            if reduction not in ("sum", "mean"):
                 raise ValueError("Reduction method can be either sum or mean")
             self.lambda_args = _lambda_args(eps, padded_value_indicator, weighing_scheme, k, sigma, mu, reduction_log)
+        self.reduction = reduction
         self.params = module._ltr_params()
         require_device(*self.params)
         dev = self.params[0].device
@@ -216,8 +214,15 @@ class FusedRanker:
         if X.dim() != 3 or X.shape[2] != info.F or tuple(y.shape[:2]) != tuple(X.shape[:2]):
             raise ValueError(f"expected X [B,S,{info.F}] and y [B,S], got {tuple(X.shape)} / {tuple(y.shape)}")
         B, S = int(X.shape[0]), int(X.shape[1])
-        if S not in (32, 64, 128):
-            raise ValueError(f"fused pass supports slate_length 32, 64 or 128 (got {S}); use net(x) + loss instead")
+        if S < 1 or S > 2048:
+            raise ValueError(f"slate_length {S} outside the supported range 1..2048")
+        lambda_mean = self.loss_kind == LOSS_LAMBDA and self.reduction == "mean"
+        if lambda_mean and world_batch not in (None, B):
+            raise NotImplementedError('lambdaLoss reduction="mean" divides by the GLOBAL kept-pair count; '
+                                      "under data parallel use reduction=\"sum\" (the reference default)")
+        # one launch when the slate tiles a 128-document super-tile; otherwise forward launch + loss kernel +
+        # backward launch (X read twice, forward recomputed) -- same flat gradient buffer either way
+        one_launch = S in (32, 64, 128) and not lambda_mean
         gb = int(world_batch) if world_batch else B
         scale = 1.0 / gb if self.loss_kind == LOSS_APPROXNDCG else 1.0     # mean (approxNDCG.py:53) vs sum (listnet.py:16)
         train = self.module.training if train is None else train
@@ -233,6 +238,8 @@ class FusedRanker:
                 self._slate = torch.empty(B, dtype=torch.float32, device=self.device)
             pack_params(self.net, self.params, out=self.packed)
             h = lib()
+            if not one_launch:
+                return self._step_three_launches(h, x2, yy, B, S, dropout, int(seed) & _MASK64, k1, k2, scale, lambda_mean)
             if self.kernel_events is not None:
                 self.kernel_events[0].record()
             if self.loss_kind == LOSS_LAMBDA:
@@ -252,4 +259,44 @@ class FusedRanker:
                   "ltr_mlp_reduce_grads")
             check(h.ltr_reduce_sum_f32(_ptr(self._slate), B, scale, self.flat.data_ptr() + 4 * self.info.n_params,
                                        _stream()), "ltr_reduce_sum_f32")
+        return self._loss_out
+
+    def _step_three_launches(self, h, x2, yy, B, S, dropout, seed, k1, k2, scale, lambda_mean):
+        """Any slate length (and lambdaLoss "mean"): scorer forward launch -> loss kernel (forward + dL/dscores)
+        -> scorer backward launch (recomputes the forward from X with the same dropout stream)."""
+        n = B * S
+        dev = self.device
+        scores = torch.empty(n, dtype=torch.float32, device=dev)
+        ds = torch.empty(n, dtype=torch.float32, device=dev)
+        check(h.ltr_mlp_forward(self.net, _ptr(x2), n, _ptr(self.packed), int(dropout), seed, _ptr(k1), _ptr(k2),
+                                _ptr(scores), self.grid, _stream()), "ltr_mlp_forward")
+        if self.loss_kind == LOSS_APPROXNDCG:
+            check(h.ltr_approxndcg_fwd_bwd(_ptr(scores), _ptr(yy), B, S, self.alpha, self.eps, self.pad, scale,
+                                           _ptr(self._slate), _ptr(ds), _stream()), "ltr_approxndcg_fwd_bwd")
+        elif self.loss_kind == LOSS_LISTNET:
+            check(h.ltr_listnet_fwd_bwd(_ptr(yy), _ptr(scores), B, S, int(self.apply_sigmoid), 1.0, _ptr(self._slate),
+                                        _ptr(ds), _stream()), "ltr_listnet_fwd_bwd")
+        else:
+            sid, kk, sigma, mu, eps, pad, lb = self.lambda_args
+            count = torch.empty(B, dtype=torch.float32, device=dev)
+            check(h.ltr_lambda_fwd_bwd(_ptr(scores), _ptr(yy), B, S, sid, max(kk, 0), sigma, mu, eps, pad, lb, 1.0,
+                                       _ptr(self._slate), _ptr(count), _ptr(ds), _stream()), "ltr_lambda_fwd_bwd")
+            if kk < 0:                       # k = 0 keeps no pair at all
+                self._slate[:B].zero_()
+                count.zero_()
+                ds.zero_()
+            if lambda_mean:
+                ds = ds / count.sum()
+        if self.kernel_events is not None:
+            self.kernel_events[0].record()
+        check(h.ltr_mlp_backward(self.net, _ptr(x2), n, _ptr(self.packed), int(dropout), seed, _ptr(k1), _ptr(k2),
+                                 _ptr(ds), _ptr(self.partials), self.grid, _stream()), "ltr_mlp_backward")
+        if self.kernel_events is not None:
+            self.kernel_events[1].record()
+        check(h.ltr_mlp_reduce_grads(self.net, _ptr(self.partials), self.grid, _ptr(self.flat_grad), _stream()),
+              "ltr_mlp_reduce_grads")
+        check(h.ltr_reduce_sum_f32(_ptr(self._slate), B, scale, self.flat.data_ptr() + 4 * self.info.n_params,
+                                   _stream()), "ltr_reduce_sum_f32")
+        if lambda_mean:
+            self._loss_out /= count.sum()
         return self._loss_out

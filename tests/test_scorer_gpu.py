@@ -185,8 +185,8 @@ def test_fused_lambda_vs_oracle(kind, S, scheme, k, sigma, log, dev):
     out = ranker.step(x.to(dev), y.to(dev))
     assert relerr(out.cpu().numpy(), rl) < TOL
     assert_grads(_grads(net), rg, ref32=rg32)
-    with pytest.raises(NotImplementedError):
-        FusedRanker(net, loss="lambdaLoss", reduction="mean")
+    with pytest.raises(ValueError, match="Reduction method can be either sum or mean"):
+        FusedRanker(net, loss="lambdaLoss", reduction="max")
     with pytest.raises(ValueError, match="Reduction logarithm base"):
         FusedRanker(net, loss="lambdaLoss", reduction_log="decimal")
 
@@ -211,6 +211,29 @@ def test_module_path_any_shape(kind, n_docs, dev):
     (O.triple_layer_forward if kind == "triple" else O.double_layer_forward)(x, p32).backward(gs)
     assert_grads(_grads(net), {k: v.grad.numpy() for k, v in p.items()},
                  ref32={k: v.grad.numpy() for k, v in p32.items()})
+
+
+@pytest.mark.parametrize("kind,S,loss,red", [("triple", 512, "lambdaLoss", "sum"), ("double", 512, "lambdaLoss", "mean"),
+                                             ("triple", 100, "approxNDCG", "sum"), ("double", 250, "listnet", "sum"),
+                                             ("triple", 128, "lambdaLoss", "mean"), ("double", 7, "approxNDCG", "sum")])
+def test_ranker_any_slate_three_launch_path(kind, S, loss, red, dev):
+    """FusedRanker.step for slates the one-launch kernel does not take (and lambdaLoss "mean"): forward launch,
+    loss kernel, backward launch into the same flat gradient buffer -- vs the fp64 oracle."""
+    from ltr_mi355x.scorer import FusedRanker
+    net, sd = _make(kind, dev, 23)
+    net.eval()
+    B = 5
+    gen = torch.Generator().manual_seed(900 + S)
+    x = torch.randn(B, S, 136, generator=gen)
+    y = torch.randint(0, 5, (B, S), generator=gen).float()
+    kw = dict(LAMBDA_KW, reduction=red)
+    rl, rg, _ = _oracle_step(kind, sd, x, y, loss, lambda_kw=kw)
+    _, rg32, _ = _oracle_step(kind, sd, x, y, loss, dtype=torch.float32, lambda_kw=kw)
+    extra = dict(weighing_scheme="ndcgLoss2PP_scheme", reduction=red) if loss == "lambdaLoss" else {}
+    ranker = FusedRanker(net, loss=loss, **extra)
+    out = ranker.step(x.to(dev), y.to(dev))
+    assert relerr(out.cpu().numpy(), rl) < TOL
+    assert_grads(_grads(net), rg, ref32=rg32)
 
 
 @pytest.mark.parametrize("kind", ["triple", "double"])
