@@ -3,8 +3,9 @@
 // A *slate group* is the set of threads (64..1024, power of two) that cooperates on one slate whose
 // state (scores, labels, gains, ...) is staged in LDS.  Rows i of the S x S pair matrix are spread over
 // `sp` row lanes, and when the group has more threads than rows the columns j are split over
-// CG = group / sp column groups; partial row sums are combined in a FIXED order through LDS so every
-// result is bit-reproducible (no float atomics anywhere in this library).
+// CG = group / sp column groups (adjacent lanes of one wave); partial row sums are combined by symmetric DPP
+// butterflies and cross-wave sums in a FIXED order through LDS, so every result is bit-reproducible (no float
+// atomics on shared accumulators anywhere in this library).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -116,25 +117,6 @@ __device__ __forceinline__ float row_reduce(const SlateGroup &g, float v) {
 #endif
     for (int o = g.CG >> 1; o >= 1; o >>= 1) v += __shfl_xor(v, o, LTR_WAVE);
     return v;
-}
-
-// Two sums at once through one pair of barriers.
-__device__ __forceinline__ void group_sum2(const SlateGroup &g, float &a, float &b) {
-    a = wave_allsum(a);
-    b = wave_allsum(b);
-    if (g.nw == 1) return;
-    __syncthreads();
-    if ((threadIdx.x & (LTR_WAVE - 1)) == 0) {
-        g.red[2 * g.wig] = a;
-        g.red[2 * g.wig + 1] = b;
-    }
-    __syncthreads();
-    a = 0.f;
-    b = 0.f;
-    for (int w = 0; w < g.nw; ++w) {
-        a += g.red[2 * w];
-        b += g.red[2 * w + 1];
-    }
 }
 
 __host__ __device__ inline int next_pow2(int v) {

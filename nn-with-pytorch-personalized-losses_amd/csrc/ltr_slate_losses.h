@@ -59,26 +59,6 @@ __device__ __forceinline__ float ideal_dcg(const SlateGroup &g, const float *yl,
 // i.e. one v_rcp per pair and no v_exp.  Wider ranges (where u would leave fp32) take the per-pair exp path.
 typedef float lds_f4 __attribute__((ext_vector_type(4)));
 
-__device__ __forceinline__ void group_minmax(const SlateGroup &g, float &lo, float &hi) {
-    lo = wave_allmin(lo);
-    hi = wave_allmax(hi);
-    if (g.nw == 1) return;
-    __syncthreads();
-    if ((threadIdx.x & (LTR_WAVE - 1)) == 0) {
-        g.red[2 * g.wig] = lo;
-        g.red[2 * g.wig + 1] = hi;
-    }
-    __syncthreads();
-    lo = g.red[0];
-    hi = g.red[1];
-    for (int w = 1; w < g.nw; ++w) {
-        lo = fminf(lo, g.red[2 * w]);
-        hi = fmaxf(hi, g.red[2 * w + 1]);
-    }
-}
-
-// JB > 0: the caller guarantees every column block is exactly JB documents (S = JB * CG, JB % 4 == 0), so the
-// pair sweeps have compile-time trip counts and unroll fully; JB == 0: general shapes.
 struct NoStamp {
     __device__ __forceinline__ void operator()(int) const {}
 };
