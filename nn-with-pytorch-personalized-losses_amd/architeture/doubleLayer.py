@@ -19,8 +19,7 @@ class DoubleLayerNet(nn.Module):
 
     def __init__(self, input_size):
         super().__init__()
-        if input_size != 136:
-            raise NotImplementedError("the gfx950 scorer kernels are compiled for 136 features (MSLR-WEB) only")
+        self._ltr_net = _scorer.net_id("double", input_size)      # 136 (MSLR-WEB) or 64 (TD2003) features
         self.fc1 = nn.Linear(input_size, input_size)
         self.fc2 = nn.Linear(input_size, input_size)
         self.fc3 = nn.Linear(input_size, 1)

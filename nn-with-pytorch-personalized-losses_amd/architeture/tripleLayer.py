@@ -13,8 +13,7 @@ class TripleLayerNet(nn.Module):
 
     def __init__(self, N_features):
         super(TripleLayerNet, self).__init__()
-        if N_features != 136:
-            raise NotImplementedError("the gfx950 scorer kernels are compiled for 136 features (MSLR-WEB) only")
+        self._ltr_net = _scorer.net_id("triple", N_features)      # 136 (MSLR-WEB) or 64 (TD2003) features
         self.l1 = nn.Linear(N_features, 64)
         self.l2 = nn.Linear(64, 32)
         self.l3 = nn.Linear(32, 1)

@@ -79,6 +79,19 @@ struct NetT {
 };
 using DoubleNet = NetT<136, 136, 136, ACT_RELU_DROP, ACT_RELU_DROP, 3, 3>;   // doubleLayer.py:54-66
 using TripleNet = NetT<136, 64, 32, ACT_ID, ACT_SIGMOID, 2, 2>;              // tripleLayer.py:5-17
+// the same classes on the reference's 64-feature collection (TD2003, utils/dataset.py:23-30)
+using DoubleNet64 = NetT<64, 64, 64, ACT_RELU_DROP, ACT_RELU_DROP, 2, 2>;
+using TripleNet64 = NetT<64, 64, 32, ACT_ID, ACT_SIGMOID, 2, 2>;
+
+// run `expr` with NET bound to the network type of id `net` (LTR_NET_*); unknown ids -> LTR_ERR_PARAM
+#define LTR_FOR_NET(net, expr)                                             \
+    switch (net) {                                                         \
+        case LTR_NET_DOUBLE: { using NET = DoubleNet; expr; } break;       \
+        case LTR_NET_TRIPLE: { using NET = TripleNet; expr; } break;       \
+        case LTR_NET_DOUBLE_64: { using NET = DoubleNet64; expr; } break;  \
+        case LTR_NET_TRIPLE_64: { using NET = TripleNet64; expr; } break;  \
+        default: return LTR_ERR_PARAM;                                     \
+    }
 
 struct PipeArgs {
     const float *X;          // [n_docs][F]
@@ -813,17 +826,9 @@ extern "C" {
 
 int ltr_net_info(int net, int32_t *info) {
     if (!info) return LTR_ERR_NULL;
-    if (net == LTR_NET_DOUBLE) {
-        info[0] = DoubleNet::F; info[1] = DoubleNet::H1; info[2] = DoubleNet::H2;
-        info[3] = DoubleNet::NPARAM; info[4] = DoubleNet::PACKED; info[5] = DoubleNet::PART;
-    } else if (net == LTR_NET_TRIPLE) {
-        info[0] = TripleNet::F; info[1] = TripleNet::H1; info[2] = TripleNet::H2;
-        info[3] = TripleNet::NPARAM; info[4] = TripleNet::PACKED; info[5] = TripleNet::PART;
-    } else {
-        return LTR_ERR_PARAM;
-    }
+    LTR_FOR_NET(net, (info[0] = NET::F, info[1] = NET::H1, info[2] = NET::H2, info[3] = NET::NPARAM,
+                      info[4] = NET::PACKED, info[5] = NET::PART, info[7] = (int32_t)pipeline_lds<NET>()))
     info[6] = kTileDocs;
-    info[7] = (int32_t)(net == LTR_NET_DOUBLE ? pipeline_lds<DoubleNet>() : pipeline_lds<TripleNet>());
     return LTR_OK;
 }
 
@@ -841,12 +846,8 @@ int ltr_mlp_pack(int net, const float *W1, const float *b1, const float *W2, con
                  const float *b3, float *packed, void *stream) {
     if (!W1 || !b1 || !W2 || !b2 || !w3 || !b3 || !packed) return LTR_ERR_NULL;
     if (!aligned16(packed)) return LTR_ERR_ALIGN;
-    if (net == LTR_NET_DOUBLE)
-        hipLaunchKernelGGL(pack_kernel<DoubleNet>, dim3(64), dim3(256), 0, (hipStream_t)stream, W1, b1, W2, b2, w3, b3, packed);
-    else if (net == LTR_NET_TRIPLE)
-        hipLaunchKernelGGL(pack_kernel<TripleNet>, dim3(64), dim3(256), 0, (hipStream_t)stream, W1, b1, W2, b2, w3, b3, packed);
-    else
-        return LTR_ERR_PARAM;
+    LTR_FOR_NET(net, hipLaunchKernelGGL(pack_kernel<NET>, dim3(64), dim3(256), 0, (hipStream_t)stream, W1, b1, W2, b2, w3,
+                                        b3, packed))
     return status();
 }
 
@@ -866,7 +867,7 @@ int ltr_debug_set_stamps(void *buf, int tile) {
 static int fill_common(PipeArgs &a, int net, const float *X, int64_t n_docs, const float *packed, int dropout,
                        uint64_t seed, const uint8_t *keep1, const uint8_t *keep2) {
     if (!X || !packed) return LTR_ERR_NULL;
-    if (net != LTR_NET_DOUBLE && net != LTR_NET_TRIPLE) return LTR_ERR_PARAM;
+    if (net < LTR_NET_DOUBLE || net > LTR_NET_TRIPLE_64) return LTR_ERR_PARAM;
     if (n_docs < 0 || n_docs > ((int64_t)1 << 37)) return LTR_ERR_SHAPE;
     if (!aligned16(X) || !aligned16(packed)) return LTR_ERR_ALIGN;
     a = PipeArgs{};
@@ -894,8 +895,8 @@ int ltr_mlp_forward(int net, const float *X, int64_t n_docs, const float *packed
     if (a.n_super == 0) return LTR_OK;
     a.scores_out = scores;
     if (grid > a.n_super) grid = a.n_super;
-    return net == LTR_NET_DOUBLE ? pipeline_dispatch<DoubleNet>(MODE_FWD, a, grid, (hipStream_t)stream)
-                                 : pipeline_dispatch<TripleNet>(MODE_FWD, a, grid, (hipStream_t)stream);
+    LTR_FOR_NET(net, return pipeline_dispatch<NET>(MODE_FWD, a, grid, (hipStream_t)stream))
+    return LTR_ERR_PARAM;
 }
 
 int ltr_mlp_backward(int net, const float *X, int64_t n_docs, const float *packed, int dropout, uint64_t seed,
@@ -907,21 +908,15 @@ int ltr_mlp_backward(int net, const float *X, int64_t n_docs, const float *packe
     if (grid < 1) return LTR_ERR_PARAM;
     a.dscores_in = dscores;
     a.partials = partials;
-    return net == LTR_NET_DOUBLE ? pipeline_dispatch<DoubleNet>(MODE_BWD, a, grid, (hipStream_t)stream)
-                                 : pipeline_dispatch<TripleNet>(MODE_BWD, a, grid, (hipStream_t)stream);
+    LTR_FOR_NET(net, return pipeline_dispatch<NET>(MODE_BWD, a, grid, (hipStream_t)stream))
+    return LTR_ERR_PARAM;
 }
 
 int ltr_mlp_reduce_grads(int net, const float *partials, int grid, float *flat_grad, void *stream) {
     if (!partials || !flat_grad) return LTR_ERR_NULL;
     if (grid < 1) return LTR_ERR_PARAM;
-    if (net == LTR_NET_DOUBLE)
-        hipLaunchKernelGGL(reduce_grads_kernel<DoubleNet>, dim3((DoubleNet::NPARAM * 8 + 255) / 256), dim3(256), 0,
-                           (hipStream_t)stream, partials, grid, flat_grad);
-    else if (net == LTR_NET_TRIPLE)
-        hipLaunchKernelGGL(reduce_grads_kernel<TripleNet>, dim3((TripleNet::NPARAM * 8 + 255) / 256), dim3(256), 0,
-                           (hipStream_t)stream, partials, grid, flat_grad);
-    else
-        return LTR_ERR_PARAM;
+    LTR_FOR_NET(net, hipLaunchKernelGGL(reduce_grads_kernel<NET>, dim3((NET::NPARAM * 8 + 255) / 256), dim3(256), 0,
+                                        (hipStream_t)stream, partials, grid, flat_grad))
     return status();
 }
 
@@ -946,8 +941,8 @@ int ltr_fused_step(int net, int loss_kind, const float *X, const float *labels, 
     a.pad = pad;
     a.gscale = grad_scale;
     a.apply_sigmoid = apply_sigmoid;
-    return net == LTR_NET_DOUBLE ? pipeline_dispatch<DoubleNet>(MODE_FUSED, a, grid, (hipStream_t)stream)
-                                 : pipeline_dispatch<TripleNet>(MODE_FUSED, a, grid, (hipStream_t)stream);
+    LTR_FOR_NET(net, return pipeline_dispatch<NET>(MODE_FUSED, a, grid, (hipStream_t)stream))
+    return LTR_ERR_PARAM;
 }
 
 int ltr_fused_step_lambda(int net, const float *X, const float *labels, int B, int S, const float *packed, int dropout,
@@ -976,8 +971,8 @@ int ltr_fused_step_lambda(int net, const float *X, const float *labels, int B, i
     a.lp.eps = eps;
     a.lp.log_scale = log_base == LTR_LOG_BINARY ? (float)(1.0 / 0.693147180559945309417) : 1.f;
     a.lp.log_floor = log_base == LTR_LOG_BINARY ? log2f(eps) : logf(eps);
-    return net == LTR_NET_DOUBLE ? pipeline_dispatch<DoubleNet>(MODE_FUSED, a, grid, (hipStream_t)stream)
-                                 : pipeline_dispatch<TripleNet>(MODE_FUSED, a, grid, (hipStream_t)stream);
+    LTR_FOR_NET(net, return pipeline_dispatch<NET>(MODE_FUSED, a, grid, (hipStream_t)stream))
+    return LTR_ERR_PARAM;
 }
 
 }  // extern "C"

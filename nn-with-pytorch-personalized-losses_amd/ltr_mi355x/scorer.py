@@ -15,7 +15,16 @@ import torch
 from ._lib import LtrError, check, lib
 from .functional import _ptr, _stream, require_device
 
-NET_DOUBLE, NET_TRIPLE = 0, 1
+NET_DOUBLE, NET_TRIPLE, NET_DOUBLE_64, NET_TRIPLE_64 = 0, 1, 2, 3
+COMPILED_FEATURES = {136: (NET_DOUBLE, NET_TRIPLE), 64: (NET_DOUBLE_64, NET_TRIPLE_64)}
+
+
+def net_id(kind, n_features):
+    """kind 'double' | 'triple' -> compiled network id for this input size."""
+    if n_features not in COMPILED_FEATURES:
+        raise NotImplementedError(f"the gfx950 scorer kernels are compiled for {sorted(COMPILED_FEATURES)} input "
+                                  f"features (MSLR-WEB / TD2003), got {n_features}")
+    return COMPILED_FEATURES[n_features][0 if kind == "double" else 1]
 LOSS_APPROXNDCG, LOSS_LISTNET, LOSS_LAMBDA = 0, 1, 2
 _MASK64 = (1 << 64) - 1
 

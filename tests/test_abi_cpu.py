@@ -76,6 +76,24 @@ def test_host_argument_contract():
         slate_2d(torch.zeros(3), "x")
 
 
+def test_scorer_modules_construct_on_cpu():
+    """state_dict keys/shapes of SURVEY 3.3 for the compiled input sizes; other sizes refuse loudly."""
+    from architeture.doubleLayer import DoubleLayerNet
+    from architeture.tripleLayer import TripleLayerNet
+    for F in (136, 64):
+        d, t = DoubleLayerNet(F), TripleLayerNet(F)
+        assert {k: tuple(v.shape) for k, v in d.state_dict().items()} == {
+            "fc1.weight": (F, F), "fc1.bias": (F,), "fc2.weight": (F, F), "fc2.bias": (F,), "fc3.weight": (1, F), "fc3.bias": (1,)}
+        assert {k: tuple(v.shape) for k, v in t.state_dict().items()} == {
+            "l1.weight": (64, F), "l1.bias": (64,), "l2.weight": (32, 64), "l2.bias": (32,), "l3.weight": (1, 32), "l3.bias": (1,)}
+        assert isinstance(d.dropout, torch.nn.Dropout) and d.dropout.p == 0.5
+    with pytest.raises(NotImplementedError):
+        DoubleLayerNet(100)
+    from ltr_mi355x import LtrDeviceError
+    with pytest.raises(LtrDeviceError):
+        TripleLayerNet(136)(torch.zeros(2, 4, 136), None, None)
+
+
 def test_module_surface_matches_reference():
     """Names/signatures of SURVEY.md section 8(b)."""
     import inspect

@@ -125,11 +125,11 @@ def _oracle_step(kind, sd, x, y, loss, k1=None, k2=None, dtype=torch.float64, la
     return l.detach().numpy(), {k: v.grad.numpy() for k, v in p.items()}, s.detach().numpy()
 
 
-def _make(kind, dev, seed):
+def _make(kind, dev, seed, F=136):
     from architeture.doubleLayer import DoubleLayerNet
     from architeture.tripleLayer import TripleLayerNet
     torch.manual_seed(seed)
-    net = TripleLayerNet(136) if kind == "triple" else DoubleLayerNet(136)
+    net = TripleLayerNet(F) if kind == "triple" else DoubleLayerNet(F)
     sd = {k: v.detach().clone() for k, v in net.state_dict().items()}
     return net.to(dev), sd
 
@@ -253,6 +253,43 @@ def test_slate512_lambda_through_modules(kind, dev):
     _, rg32, _ = _oracle_step(kind, sd, x, y, "lambdaLoss", dtype=torch.float32)
     assert relerr(loss.detach().cpu().numpy(), rl) < TOL
     assert_grads(_grads(net), rg, ref32=rg32)
+
+
+@pytest.mark.parametrize("kind", ["triple", "double"])
+@pytest.mark.parametrize("S", [32, 128, 50])
+def test_64_feature_nets(kind, S, dev):
+    """The same classes on the reference's 64-feature collection (TD2003): module path and fused pass."""
+    from losses.approxNDCG import approxNDCGLoss
+    from ltr_mi355x.scorer import FusedRanker
+    net, sd = _make(kind, dev, 31, F=64)
+    assert [tuple(p.shape) for p in net.parameters()][0][1] == 64
+    B = 6
+    gen = torch.Generator().manual_seed(64 + S)
+    x = torch.randn(B, S, 64, generator=gen)
+    y = torch.randint(0, 5, (B, S), generator=gen).float()
+    k1 = k2 = None
+    if kind == "double":
+        net.train()
+        k1 = (torch.rand(B, S, 64, generator=gen) < 0.5).float()
+        k2 = (torch.rand(B, S, 64, generator=gen) < 0.5).float()
+    rl, rg, _ = _oracle_step(kind, sd, x, y, "approxNDCG", k1, k2)
+    _, rg32, _ = _oracle_step(kind, sd, x, y, "approxNDCG", k1, k2, dtype=torch.float32)
+    ranker = FusedRanker(net, loss="approxNDCG")
+    out = ranker.step(x.to(dev), y.to(dev), keep1=None if k1 is None else k1.to(dev), keep2=None if k2 is None else k2.to(dev))
+    assert relerr(out.cpu().numpy(), rl) < TOL
+    assert_grads(_grads(net), rg, ref32=rg32)
+    # module path (forward launch + loss kernel + backward launch) gives the same gradients
+    fused = {k: v.copy() for k, v in _grads(net).items()}
+    for p in net.parameters():
+        p.grad = None
+    if kind == "double":
+        scores = net(x.to(dev), None, None, keep1=k1.to(dev), keep2=k2.to(dev))
+    else:
+        scores = net(x.to(dev), None, None)
+    approxNDCGLoss(scores.squeeze(-1), y.to(dev)).backward()
+    assert_grads(_grads(net), fused, 1e-5)
+    with pytest.raises(NotImplementedError):
+        _make(kind, dev, 1, F=100)
 
 
 def test_dropout_stream(dev):
