@@ -263,37 +263,93 @@ __host__ __device__ constexpr int dw_col(int g) { return (g % (NC * BH)) / BH; }
 // dW tiles of wave W += A^T B over one 64-document chunk.
 //   a_base / b_base: this lane's LDS addresses of A[row q][16*0 + i] / B[row q][16*0 + i] for k-step 0;
 //   k-step s adds 4*LD floats; tile (To, Ti) adds 16*To / 16*Ti floats: all immediates.
+template <int W, int TW, int NR, int NC, int BH>
+struct DwSet {   // which A (row) / B (column) fragments wave W's tile set touches
+    static constexpr bool uses_row(int To) {
+        for (int j = 0; j < TW; ++j)
+            if (W * TW + j < NR * NC && dw_row<NR, NC, BH>(W * TW + j) == To) return true;
+        return false;
+    }
+    static constexpr bool uses_col(int Ti) {
+        for (int j = 0; j < TW; ++j)
+            if (W * TW + j < NR * NC && dw_col<NR, NC, BH>(W * TW + j) == Ti) return true;
+        return false;
+    }
+    static constexpr int n_frags() {
+        int n = 0;
+        for (int t = 0; t < NR; ++t) n += uses_row(t) ? 1 : 0;
+        for (int t = 0; t < NC; ++t) n += uses_col(t) ? 1 : 0;
+        return n;
+    }
+    static constexpr int n_tiles() {
+        int n = 0;
+        for (int j = 0; j < TW; ++j) n += (W * TW + j < NR * NC) ? 1 : 0;
+        return n;
+    }
+};
+
+template <int W, int TW, int NR, int NC, int BH, int LD>
+__device__ __forceinline__ void dw_load(float (&af)[NR], float (&bf)[NC], const float *ar, const float *br) {
+#pragma unroll
+    for (int To = 0; To < NR; ++To)
+        if (DwSet<W, TW, NR, NC, BH>::uses_row(To)) af[To] = ar[16 * To];
+#pragma unroll
+    for (int Ti = 0; Ti < NC; ++Ti)
+        if (DwSet<W, TW, NR, NC, BH>::uses_col(Ti)) bf[Ti] = br[16 * Ti];
+}
+
+template <int W, int TW, int NR, int NC, int BH>
+__device__ __forceinline__ void dw_mfma(f32x4 (&acc)[TW], const float (&af)[NR], const float (&bf)[NC]) {
+#pragma unroll
+    for (int j = 0; j < TW; ++j) {
+        const int g = W * TW + j;
+        if (g < NR * NC) acc[j] = mfma4(af[dw_row<NR, NC, BH>(g)], bf[dw_col<NR, NC, BH>(g)], acc[j]);
+    }
+}
+
+#ifndef LTR_DW_PIPE
+#define LTR_DW_PIPE 0
+#endif
+#ifndef LTR_H1_BITS
+#define LTR_H1_BITS 0
+#endif
+
 template <int W, int TW, int NR, int NC, int BH, int LD>
 __device__ __forceinline__ void dw_chunk_w(f32x4 (&acc)[TW], const float *a_base, const float *b_base) {
-    constexpr int NTOT = NR * NC;
-    for (int s = 0; s < kChunkDocs / 4; ++s) {
-        const float *ar = a_base + s * 4 * LD;
-        const float *br = b_base + s * 4 * LD;
-        float af[NR], bf[NC];
+    constexpr int KS = kChunkDocs / 4;
+#if LTR_DW_PIPE
+    // Fragments double-buffered and the interleave PINNED (one LDS read per MFMA): the reads of k-step s+1 are in
+    // flight under the MFMAs of k-step s.  (Left to itself hipcc sinks the reads next to their use and waits
+    // lgkmcnt(0) every 5-6 MFMAs.)
+    constexpr int NF = DwSet<W, TW, NR, NC, BH>::n_frags();
+    constexpr int NM = DwSet<W, TW, NR, NC, BH>::n_tiles();
+    float af0[NR], bf0[NC], af1[NR], bf1[NC];
+    dw_load<W, TW, NR, NC, BH, LD>(af0, bf0, a_base, b_base);
 #pragma unroll
-        for (int j = 0; j < TW; ++j) {
-            constexpr int dummy = 0;
-            (void)dummy;
-            const int g = W * TW + j;
-            if (g < NTOT) {
-                const int To = dw_row<NR, NC, BH>(g), Ti = dw_col<NR, NC, BH>(g);
-                bool first_a = true, first_b = true;
+    for (int s = 0; s < KS; s += 2) {
+        dw_load<W, TW, NR, NC, BH, LD>(af1, bf1, a_base + (s + 1) * 4 * LD, b_base + (s + 1) * 4 * LD);
+        dw_mfma<W, TW, NR, NC, BH>(acc, af0, bf0);
 #pragma unroll
-                for (int jj = 0; jj < j; ++jj) {
-                    const int g2 = W * TW + jj;
-                    if (dw_row<NR, NC, BH>(g2) == To) first_a = false;
-                    if (dw_col<NR, NC, BH>(g2) == Ti) first_b = false;
-                }
-                if (first_a) af[To] = ar[16 * To];
-                if (first_b) bf[Ti] = br[16 * Ti];
-            }
+        for (int i = 0; i < (NM > NF ? NM : NF); ++i) {
+            if (i < NF) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // 1 DS read
+            if (i < NM) __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // 1 MFMA
         }
+        if (s + 2 < KS)
+            dw_load<W, TW, NR, NC, BH, LD>(af0, bf0, a_base + (s + 2) * 4 * LD, b_base + (s + 2) * 4 * LD);
+        dw_mfma<W, TW, NR, NC, BH>(acc, af1, bf1);
 #pragma unroll
-        for (int j = 0; j < TW; ++j) {
-            const int g = W * TW + j;
-            if (g < NTOT) acc[j] = mfma4(af[dw_row<NR, NC, BH>(g)], bf[dw_col<NR, NC, BH>(g)], acc[j]);
+        for (int i = 0; i < (NM > NF ? NM : NF); ++i) {
+            if (i < NF && s + 2 < KS) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            if (i < NM) __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
         }
     }
+#else
+    for (int s = 0; s < KS; ++s) {
+        float af[NR], bf[NC];
+        dw_load<W, TW, NR, NC, BH, LD>(af, bf, a_base + s * 4 * LD, b_base + s * 4 * LD);
+        dw_mfma<W, TW, NR, NC, BH>(acc, af, bf);
+    }
+#endif
 }
 
 template <int TW, int NR, int NC, int BH, int LD>
@@ -616,6 +672,19 @@ __global__ void __launch_bounds__(kThreads, 2) slate_pipeline_kernel(const PipeA
             }
         }
         // h2 now holds dz2.
+#if LTR_H1_BITS
+        // From here on h1 is needed as a VALUE only by the dW2 staging; the dz1 mask needs just sign(h1) for
+        // ReLU layers: keep NT1*4 sign bits (2 VGPRs) so the 36 h1 registers are dead during the dh1 GEMM,
+        // the register-pressure peak of the kernel.
+        unsigned hbits[(N::NT1 * 4 + 31) / 32] = {};
+        if (N::A1 == ACT_RELU_DROP) {
+#pragma unroll
+            for (int To = 0; To < N::NT1; ++To)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    hbits[(To * 4 + r) >> 5] |= (h1[To][r] > 0.f ? 1u : 0u) << ((To * 4 + r) & 31);
+        }
+#endif
         LTR_STAMP(6)
         // ---- dW2 += dz2^T [h1 | 1] over the two 64-document chunks (tiles of waves 0-3, then waves 4-7)
 #pragma unroll
@@ -646,7 +715,13 @@ __global__ void __launch_bounds__(kThreads, 2) slate_pipeline_kernel(const PipeA
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const float gsc = (N::A1 == ACT_RELU_DROP) ? dz1[To][r] * slope : dz1[To][r];
+#if LTR_H1_BITS
+                float v = (N::A1 == ACT_RELU_DROP)
+                              ? (((hbits[(To * 4 + r) >> 5] >> ((To * 4 + r) & 31)) & 1u) ? gsc : 0.f)
+                              : apply_act_grad<N::A1>(gsc, h1[To][r]);
+#else
                 float v = apply_act_grad<N::A1>(gsc, h1[To][r]);
+#endif
                 if (16 * To + 16 > N::H1) v = (16 * To + 4 * q + r < N::H1) ? v : 0.f;   // last tile only
                 dz1[To][r] = v;
             }
