@@ -232,6 +232,13 @@ class FusedRanker:
         # one launch when the slate tiles a 128-document super-tile; otherwise forward launch + loss kernel +
         # backward launch (X read twice, forward recomputed) -- same flat gradient buffer either way
         one_launch = S in (32, 64, 128) and not lambda_mean
+        if B == 0:
+            # no slates on this rank: zero gradient contribution; the loss of an empty batch is what the
+            # reference's reduction gives (mean of nothing = nan, sum of nothing = 0) unless a global batch is set
+            self.flat.zero_()
+            if self.loss_kind == LOSS_APPROXNDCG and not world_batch:
+                self.flat[self.info.n_params] = float("nan")
+            return self._loss_out
         gb = int(world_batch) if world_batch else B
         scale = 1.0 / gb if self.loss_kind == LOSS_APPROXNDCG else 1.0     # mean (approxNDCG.py:53) vs sum (listnet.py:16)
         train = self.module.training if train is None else train

@@ -292,6 +292,40 @@ def test_64_feature_nets(kind, S, dev):
         _make(kind, dev, 1, F=100)
 
 
+def test_fused_edge_cases(dev):
+    """Empty batch, a batch smaller than one 128-document tile, X handed over as a misaligned / strided view,
+    and slates that are entirely padding."""
+    from ltr_mi355x.scorer import FusedRanker
+    net, sd = _make("triple", dev, 41)
+    ranker = FusedRanker(net, loss="approxNDCG")
+    # empty batch: nothing to do, gradients are zero
+    out = ranker.step(torch.zeros(0, 32, 136, device=dev), torch.zeros(0, 32, device=dev))
+    assert float(ranker.flat_grad.abs().max()) == 0.0 and torch.isnan(out)      # mean over no slates
+    out = ranker.step(torch.zeros(0, 32, 136, device=dev), torch.zeros(0, 32, device=dev), world_batch=64)
+    assert float(out) == 0.0                                                      # a rank without slates adds nothing
+    gen = torch.Generator().manual_seed(3)
+    B, S = 3, 32                                                    # 96 documents < one tile
+    big = torch.randn(B * S * 136 + 1, generator=gen)
+    x = big[1:].view(B, S, 136)                                     # 4-byte-offset view: not 16-byte aligned
+    y = torch.randint(0, 5, (B, S), generator=gen).float()
+    y[1] = -1.0                                                     # one slate is all padding
+    rl, rg, _ = _oracle_step("triple", sd, x, y, "approxNDCG")
+    xd = big.to(dev)[1:].view(B, S, 136)
+    assert xd.data_ptr() % 16 != 0
+    out = ranker.step(xd, y.to(dev))
+    assert relerr(out.cpu().numpy(), rl) < TOL
+    assert_grads(_grads(net), rg)
+    xs = torch.randn(B, S, 272, generator=gen)[:, :, ::2]           # strided (non-contiguous) features
+    rl, rg, _ = _oracle_step("triple", sd, xs, y, "approxNDCG")
+    out = ranker.step(xs.to(dev), y.double().to(dev))               # fp64 labels, like the reference loader
+    assert relerr(out.cpu().numpy(), rl) < TOL
+    assert_grads(_grads(net), rg)
+    with pytest.raises(ValueError):
+        ranker.step(torch.zeros(2, 32, 100, device=dev), torch.zeros(2, 32, device=dev))
+    with pytest.raises(TypeError):
+        ranker.step(torch.zeros(2, 32, 136, device=dev, dtype=torch.float64), torch.zeros(2, 32, device=dev))
+
+
 def test_dropout_stream(dev):
     """The counter-based dropout stream: ~Bernoulli(0.5), layer/seed dependent, and the forward under it
     equals the oracle forward under the exported masks; fused == unfused for the same seed."""
