@@ -425,6 +425,10 @@ __device__ __forceinline__ void load_x_tile(f32x4 (&xr)[kXV4<N>()], const PipeAr
 #ifndef LTR_XDMA
 #define LTR_XDMA 1
 #endif
+#ifndef LTR_X_AUX
+#define LTR_X_AUX 2              // cache policy of the X stream: 2 = nt (read once by one CU: keeps the L2-resident weight
+                                 // fragments from being evicted; FETCH_SIZE -16 % at equal time), 0 = default
+#endif
 // X: HBM/L2 -> LDS by LDS-DMA (global_load_lds, 16 B per lane, no VGPRs, no address math): one wave-instruction
 // per document row, lanes 0..F/4-1 active, destination = row base + lane*16 (rows keep their padded LD stride;
 // the pad columns -- ones feature + zeros -- are constant and written once per kernel).  Rows past the end of
@@ -440,7 +444,7 @@ __device__ __forceinline__ void dma_x_rows(const PipeArgs &a, float *Xs, long lo
         float *dst = Xs + (16 * w + r) * N::LD;                 // wave-uniform
         if (row0 + r < a.n_docs) {                               // wave-uniform
             if (lane < N::F / 4)
-                __builtin_amdgcn_global_load_lds((gptr_t)(a.X + (row0 + r) * N::F + 4 * lane), (lptr_t)dst, 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((gptr_t)(a.X + (row0 + r) * N::F + 4 * lane), (lptr_t)dst, 16, 0, LTR_X_AUX);
         } else if (lane < N::F / 4) {
             *reinterpret_cast<f32x4 *>(dst + 4 * lane) = f32x4{0.f, 0.f, 0.f, 0.f};
         }
