@@ -107,6 +107,24 @@ def cpu_baseline(net_kind, S, budget_s=12.0):
                       "oracle restatement of the reference's torch-CPU path (no dX, unlike the reference)"}
 
 
+def self_launch(n):
+    """`python bench.py --gpus N` without a launcher: this parent has made NO GPU call (it only parsed arguments);
+    it starts the N ranks as a child `torch.distributed.run` (never exec from a GPU-touched process), relays
+    their output -- rank 0's JSON line included -- and exits with the children's status."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // n)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    rc = subprocess.run(cmd, env=env).returncode
+    sys.exit(rc)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -125,6 +143,8 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return self_launch(a.gpus)
     if world != a.gpus:
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {a.gpus}")
     import torch.distributed as dist
@@ -152,14 +172,13 @@ def main():
     Q, S, B = a.queries, a.slate, min(a.batch, a.queries)
     X, y = synth(Q, S, dev, 2020 + rank)
     ranker = FusedRanker(net, loss=a.loss, **({"weighing_scheme": "ndcgLoss2PP_scheme"} if a.loss == "lambdaLoss" else {}))
-    ranker.seed_salt = rank
     opt = torch.optim.Adam(net.parameters(), lr=1e-3, fused=True)
     trainer = QueryShardedTrainer(ranker, opt)
     n_win = max(1, Q // B)
 
     def step(i):
         lo = (i % n_win) * B
-        return trainer.step(X[lo:lo + B], y[lo:lo + B])
+        return trainer.step(X[lo:lo + B], y[lo:lo + B], global_batch=B * world)   # equal shards: no size collective
 
     for i in range(a.warmup):
         step(i)

@@ -115,8 +115,16 @@ struct PipeArgs {
     int n_super;
     unsigned long long *stamps;   // diagnostic build (-DLTR_STAMPS) only: [grid][8 waves][16] s_memtime values
     int stamp_tile;               // ... of this workgroup-local tile iteration
-    int debug_skip;          // timing experiments only (env LTR_DEBUG_SKIP): 1 loss, 2 dW GEMMs, 4 dh1, 8 fc2, 16 fc1
+    int debug_skip;          // diagnostic builds (-DLTR_DIAG) only: 1 loss, 2 dW GEMMs, 4 dh1, 8 fc2, 16 fc1 skipped
 };
+
+// Phase-ablation switch for timing experiments (results are WRONG when a phase is skipped): compiled in only
+// under -DLTR_DIAG, like the phase stamps under -DLTR_STAMPS.  The shipped library has no such switch.
+#ifdef LTR_DIAG
+#define LTR_SKIP(a, bit) ((a).debug_skip & (bit))
+#else
+#define LTR_SKIP(a, bit) 0
+#endif
 
 __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
@@ -562,7 +570,7 @@ __global__ void __launch_bounds__(kThreads, 2) slate_pipeline_kernel(const PipeA
             for (int T = 0; T < N::XT; ++T)
                 xb[T] = *reinterpret_cast<const f32x4 *>(Xs + my_row * LD + 16 * T + 4 * q);
             if (N::H1T > N::NT1) h1[N::H1T - 1] = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (!(a.debug_skip & 16)) gemm_wx<N::NT1, N::XT>(wrsrc, N::W1F_OFF * 4, lane_off, xb, h1);
+            if (!LTR_SKIP(a, 16)) gemm_wx<N::NT1, N::XT>(wrsrc, N::W1F_OFF * 4, lane_off, xb, h1);
             else
 #pragma unroll
                 for (int To = 0; To < N::NT1; ++To) h1[To] = xb[To];
@@ -575,7 +583,7 @@ __global__ void __launch_bounds__(kThreads, 2) slate_pipeline_kernel(const PipeA
         LTR_STAMP(2)
         // ---- fc2
         f32x4 h2[N::NT2];
-        if (!(a.debug_skip & 8)) gemm_wx<N::NT2, N::H1T>(wrsrc, N::W2F_OFF * 4, lane_off, h1, h2);
+        if (!LTR_SKIP(a, 8)) gemm_wx<N::NT2, N::H1T>(wrsrc, N::W2F_OFF * 4, lane_off, h1, h2);
         else
 #pragma unroll
             for (int To = 0; To < N::NT2; ++To) h2[To] = h1[To];
@@ -601,7 +609,7 @@ __global__ void __launch_bounds__(kThreads, 2) slate_pipeline_kernel(const PipeA
         }
         LTR_STAMP(4)
         // ---- listwise loss on the LDS-resident scores (fused) -> dsc
-        if (MODE == MODE_FUSED && (a.debug_skip & 1)) {
+        if (MODE == MODE_FUSED && LTR_SKIP(a, 1)) {
             __syncthreads();
             if (tid < kTileDocs) dsc[tid] = 1e-3f * sc[tid];
         } else if (MODE == MODE_FUSED) {
@@ -703,14 +711,14 @@ __global__ void __launch_bounds__(kThreads, 2) slate_pipeline_kernel(const PipeA
                     *reinterpret_cast<f32x4 *>(Hs + crow * LD + 16 * T + 4 * q) = h1[T];
             }
             __syncthreads();
-            if (!(a.debug_skip & 2))
+            if (!LTR_SKIP(a, 2))
                 dw_chunk<N::TW2, N::NT2, N::H1T, N::BH2, LD>(w, accW2, Ds + q * LD + d, Hs + q * LD + d);
         }
         LTR_STAMP(7)
         // ---- dh1^T = W2^T dz2^T  (A = packed W2^T fragments, B = dz2 registers), then
         //      dz1 = dh1 * act1'(h1), features >= H1 (incl. the ones feature) zeroed
         f32x4 dz1[N::NT1];
-        if (!(a.debug_skip & 4)) gemm_wx<N::NT1, N::NT2>(wrsrc, N::W2T_OFF * 4, lane_off, h2, dz1);
+        if (!LTR_SKIP(a, 4)) gemm_wx<N::NT1, N::NT2>(wrsrc, N::W2T_OFF * 4, lane_off, h2, dz1);
         else
 #pragma unroll
             for (int To = 0; To < N::NT1; ++To) dz1[To] = h2[To < N::NT2 ? To : 0];
@@ -743,7 +751,7 @@ __global__ void __launch_bounds__(kThreads, 2) slate_pipeline_kernel(const PipeA
             for (int To = 0; To < N::NT1; ++To)
                 *reinterpret_cast<f32x4 *>(Ds + my_row * LD + 16 * To + 4 * q) = dz1[To];
             __syncthreads();
-            if (!(a.debug_skip & 2)) {
+            if (!LTR_SKIP(a, 2)) {
 #pragma unroll
                 for (int c = 0; c < 2; ++c)
                     dw_chunk<N::TW1, N::NT1, N::XT, N::BH1, LD>(w, accW1, Ds + (64 * c + q) * LD + d,
@@ -759,7 +767,7 @@ __global__ void __launch_bounds__(kThreads, 2) slate_pipeline_kernel(const PipeA
                         *reinterpret_cast<f32x4 *>(Ds + crow * LD + 16 * To + 4 * q) = dz1[To];
                 }
                 __syncthreads();
-                if (!(a.debug_skip & 2))
+                if (!LTR_SKIP(a, 2))
                     dw_chunk<N::TW1, N::NT1, N::XT, N::BH1, LD>(w, accW1, Ds + q * LD + d, Xs + (64 * c + q) * LD + d);
             }
         }
@@ -831,9 +839,11 @@ template <class N>
 __global__ void reduce_grads_kernel(const float *__restrict__ partials, int nparts, float *__restrict__ flat) {
     // 8 lanes per parameter: lane s sums partials s, s+8, s+16, ... (independent loads in flight), then the 8
     // strided sums are combined by a fixed butterfly -> same bits on every run, ~8x less serial latency.
+    // The cross-workgroup sum runs in fp64 (37 k parameters x 256 partials: free) so the only fp32 rounding left
+    // in a parameter gradient is the per-workgroup MFMA accumulation chain.
     const int gt = blockIdx.x * blockDim.x + threadIdx.x;
     const int e = gt >> 3, sub = gt & 7;
-    float s = 0.f;
+    double s = 0.0;
     if (e < N::NPARAM) {
         int off;
         int k = e;
@@ -850,12 +860,12 @@ __global__ void reduce_grads_kernel(const float *__restrict__ partials, int npar
         } else {
             off = N::P_B3;
         }
-        for (int p = sub; p < nparts; p += 8) s += partials[(size_t)p * N::PART + off];
+        for (int p = sub; p < nparts; p += 8) s += (double)partials[(size_t)p * N::PART + off];
     }
     s += __shfl_xor(s, 1, 64);
     s += __shfl_xor(s, 2, 64);
     s += __shfl_xor(s, 4, 64);
-    if (e < N::NPARAM && sub == 0) flat[e] = s;
+    if (e < N::NPARAM && sub == 0) flat[e] = (float)s;
 }
 
 template <class N>
@@ -872,12 +882,15 @@ inline int status() {
 template <class N, int MODE, int LOSS>
 int launch_pipeline(const PipeArgs &a, int grid, hipStream_t stream) {
     constexpr size_t lds = pipeline_lds<N>();
-    static bool attr_done = false;
-    if (!attr_done) {
+    // the dynamic-LDS limit is a per-DEVICE function attribute: remember it per device, not per process
+    static bool attr_done[64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = -1;
+    if (dev < 0 || !attr_done[dev]) {
         hipError_t e = hipFuncSetAttribute((const void *)slate_pipeline_kernel<N, MODE, LOSS>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
-        attr_done = true;
+        if (dev >= 0) attr_done[dev] = true;
     }
     hipLaunchKernelGGL((slate_pipeline_kernel<N, MODE, LOSS>), dim3(grid), dim3(kThreads), lds, stream, a);
     return status();
@@ -958,8 +971,10 @@ static int fill_common(PipeArgs &a, int net, const float *X, int64_t n_docs, con
     a.keep1 = keep1;
     a.keep2 = keep2;
     a.n_super = (int)((n_docs + kTileDocs - 1) / kTileDocs);
+#ifdef LTR_DIAG
     static const int dbg = getenv("LTR_DEBUG_SKIP") ? atoi(getenv("LTR_DEBUG_SKIP")) : 0;
     a.debug_skip = dbg;
+#endif
     a.stamps = g_stamps;
     a.stamp_tile = g_stamp_tile;
     return LTR_OK;

@@ -47,11 +47,26 @@ class QueryShardedTrainer:
         self.opt = optimizer
         self.group = group
         self.rank, self.world_size = world()
+        # every rank draws its OWN dropout stream: the keep bits are keyed on (seed, local document index), so
+        # without a per-rank salt document i of every shard would share one mask (ltr_scorer.hip keep_word)
+        if hasattr(self.local, "seed_salt"):
+            self.local.seed_salt = self.rank
+
+    def global_batch_of(self, b_local, device):
+        """Sum of the ranks' local batch sizes (one 8-byte all-reduce + host read).  `shard_range` shards differ by
+        one slate, so B_local * world_size is wrong for ragged shards; callers with equal shards pass
+        `global_batch` to `step` and skip this collective (bench.py does)."""
+        if self.world_size == 1:
+            return b_local
+        t = torch.tensor([b_local], dtype=torch.int64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+        return int(t.item())
 
     def step(self, X, y, global_batch=None):
         """One optimizer step on this rank's slates.  Returns the GLOBAL loss (0-dim tensor, no host sync).
-        global_batch defaults to B_local * world_size (equal shards)."""
-        gb = int(global_batch) if global_batch else int(X.shape[0]) * self.world_size
+        global_batch: total slates over all ranks this step; default = all-reduced sum of the local sizes
+        (every rank must then take the default, or every rank pass the value)."""
+        gb = int(global_batch) if global_batch else self.global_batch_of(int(X.shape[0]), X.device)
         self.local.step(X, y, world_batch=gb)
         if self.world_size > 1:
             dist.all_reduce(self.local.flat, op=dist.ReduceOp.SUM, group=self.group)

@@ -203,10 +203,12 @@ class FusedRanker:
         # one flat fp32 buffer [all parameter gradients | loss]: the ONLY thing data parallel all-reduces
         self.flat = torch.zeros(self.info.n_params + 1, dtype=torch.float32, device=dev)
         self.flat_grad = self.flat[:self.info.n_params]
+        self._grad_views = []
         off = 0
         for p in self.params:           # every p.grad is a view into the flat buffer
-            p.grad = self.flat_grad[off:off + p.numel()].view_as(p)
+            self._grad_views.append(self.flat_grad[off:off + p.numel()].view_as(p))
             off += p.numel()
+        self._bind_grads()
         self.packed = torch.empty(self.info.packed_floats, dtype=torch.float32, device=dev)
         self.partials = torch.empty(self.grid * self.info.partial_floats, dtype=torch.float32, device=dev)
         self._loss_out = self.flat[self.info.n_params]
@@ -214,6 +216,16 @@ class FusedRanker:
         self._calls = 0
         self.seed_salt = 0             # per-rank salt of the dropout stream (data parallel)
         self.kernel_events = None      # optional (start, end) torch.cuda.Event pair bracketing the pipeline kernel
+
+    def _bind_grads(self):
+        """Make every `param.grad` the view of the flat buffer again.  `opt.zero_grad()` / `net.zero_grad()` default
+        to set_to_none=True (they drop the aliasing) and the reference loop calls zero_grad between the loss and
+        backward (main_batch_execution.py:167): re-binding at the end of every step keeps `opt.step()` correct
+        whichever side of `ranker.step` the caller zeroes on.  (zero_grad(set_to_none=False) AFTER step() would
+        wipe the gradients just computed -- like zeroing after backward() in any torch loop.)"""
+        for p, v in zip(self.params, self._grad_views):
+            if p.grad is not v:
+                p.grad = v
 
     def step(self, X, y, world_batch=None, keep1=None, keep2=None, seed=None, train=None):
         """Run the fused pass on this rank's slates.  Returns the 0-dim LOCAL loss contribution, already
@@ -238,6 +250,15 @@ class FusedRanker:
             self.flat.zero_()
             if self.loss_kind == LOSS_APPROXNDCG and not world_batch:
                 self.flat[self.info.n_params] = float("nan")
+            self._bind_grads()
+            return self._loss_out
+        if self.loss_kind == LOSS_LAMBDA and self.lambda_args[1] < 0:
+            # k = 0: `ndcg_at_k_mask[:0, :0]` keeps no pair (lambdaL.py:29-30) -> loss 0 ("sum") / nan ("mean" of
+            # nothing), zero gradient, for every slate length
+            self.flat.zero_()
+            if lambda_mean:
+                self.flat[self.info.n_params] = float("nan")
+            self._bind_grads()
             return self._loss_out
         gb = int(world_batch) if world_batch else B
         scale = 1.0 / gb if self.loss_kind == LOSS_APPROXNDCG else 1.0     # mean (approxNDCG.py:53) vs sum (listnet.py:16)
@@ -255,7 +276,9 @@ class FusedRanker:
             pack_params(self.net, self.params, out=self.packed)
             h = lib()
             if not one_launch:
-                return self._step_three_launches(h, x2, yy, B, S, dropout, int(seed) & _MASK64, k1, k2, scale, lambda_mean)
+                out = self._step_three_launches(h, x2, yy, B, S, dropout, int(seed) & _MASK64, k1, k2, scale, lambda_mean)
+                self._bind_grads()
+                return out
             if self.kernel_events is not None:
                 self.kernel_events[0].record()
             if self.loss_kind == LOSS_LAMBDA:
@@ -275,6 +298,7 @@ class FusedRanker:
                   "ltr_mlp_reduce_grads")
             check(h.ltr_reduce_sum_f32(_ptr(self._slate), B, scale, self.flat.data_ptr() + 4 * self.info.n_params,
                                        _stream()), "ltr_reduce_sum_f32")
+        self._bind_grads()
         return self._loss_out
 
     def _step_three_launches(self, h, x2, yy, B, S, dropout, seed, k1, k2, scale, lambda_mean):
@@ -295,12 +319,8 @@ class FusedRanker:
         else:
             sid, kk, sigma, mu, eps, pad, lb = self.lambda_args
             count = torch.empty(B, dtype=torch.float32, device=dev)
-            check(h.ltr_lambda_fwd_bwd(_ptr(scores), _ptr(yy), B, S, sid, max(kk, 0), sigma, mu, eps, pad, lb, 1.0,
+            check(h.ltr_lambda_fwd_bwd(_ptr(scores), _ptr(yy), B, S, sid, kk, sigma, mu, eps, pad, lb, 1.0,
                                        _ptr(self._slate), _ptr(count), _ptr(ds), _stream()), "ltr_lambda_fwd_bwd")
-            if kk < 0:                       # k = 0 keeps no pair at all
-                self._slate[:B].zero_()
-                count.zero_()
-                ds.zero_()
             if lambda_mean:
                 ds = ds / count.sum()
         if self.kernel_events is not None:

@@ -31,6 +31,7 @@ class OracleLocalStep:
         self.params = params
         n = sum(p.numel() for p in params)
         self.flat = torch.zeros(n + 1, dtype=torch.float64)
+        self.seed_salt = -1        # QueryShardedTrainer must set the per-rank dropout salt
         off = 0
         for p in params:
             p.grad = self.flat[off:off + p.numel()].view_as(p)
@@ -79,6 +80,10 @@ def _worker(rank, world, port, out_dir):
     losses = []
     for _ in range(3):
         losses.append(float(tr.step(X[lo:hi], y[lo:hi], global_batch=X.shape[0])))
+    assert local.seed_salt == rank
+    # ragged shards (11 queries over 2 ranks: 6 + 5) with the DEFAULT global batch = all-reduced local sizes
+    lo, hi = shard_range(11, rank, world)
+    losses.append(float(tr.step(X[lo:hi], y[lo:hi])))
     torch.save({"losses": losses, "flat": local.flat.clone(), "params": [p.detach().clone() for p in params]},
                os.path.join(out_dir, f"rank{rank}.pt"))
     dist.destroy_process_group()
@@ -107,6 +112,9 @@ def test_two_rank_allreduce_equals_single_process():
         local.step(X, y)
         ref_losses.append(float(local.flat[-1]))
         opt.step()
+    local.step(X[:11], y[:11])
+    ref_losses.append(float(local.flat[-1]))
+    opt.step()
     assert r0["losses"] == r1["losses"]
     assert torch.allclose(torch.tensor(r0["losses"]), torch.tensor(ref_losses), rtol=1e-12, atol=0)
     assert torch.equal(r0["flat"], r1["flat"])

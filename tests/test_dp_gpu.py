@@ -83,3 +83,82 @@ def test_two_ranks_one_gpu_equals_single_process():
     for a, b, c in zip(r0["params"], r1["params"], net.parameters()):
         assert torch.equal(a, b)
         assert float((a - c.detach().cpu()).abs().max()) / max(float(c.abs().max()), 1e-30) < 1e-5
+
+
+def _dropout_worker(rank, world, port, out_dir):
+    """DoubleLayerNet in TRAIN mode under data parallel: the trainer gives every rank its own dropout stream."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dev = torch.device("cuda:0")
+    sys.path.insert(0, os.path.join(ROOT, "nn-with-pytorch-personalized-losses_amd"))
+    from architeture.doubleLayer import DoubleLayerNet
+    from ltr_mi355x import scorer
+    from ltr_mi355x.dp import QueryShardedTrainer, shard_range, sync_parameters
+    torch.manual_seed(2020)
+    net = DoubleLayerNet(136).to(dev)
+    net.train()
+    sync_parameters(net)
+    ranker = scorer.FusedRanker(net, loss="approxNDCG")
+    tr = QueryShardedTrainer(ranker, torch.optim.SGD(net.parameters(), lr=0.1))
+    assert ranker.seed_salt == rank
+    X, y = _data()
+    lo, hi = shard_range(X.shape[0], rank, world)
+    n_local = (hi - lo) * X.shape[1]
+    # the seed step() will draw for its first call (same formula as FusedRanker.step)
+    seed = scorer.next_seed(0) ^ ((ranker.seed_salt * 0xA24BAED4963EE407) & ((1 << 64) - 1))
+    m1 = scorer.dropout_keep_mask(seed, 0, n_local, 136, dev).cpu()
+    m2 = scorer.dropout_keep_mask(seed, 1, n_local, 136, dev).cpu()
+    w0 = [p.detach().clone() for p in net.parameters()]
+    loss = float(tr.step(X[lo:hi].to(dev), y[lo:hi].to(dev)))           # default global batch (all-reduced sizes)
+    torch.save({"loss": loss, "flat": ranker.flat.cpu(), "m1": m1, "m2": m2, "lo": lo, "hi": hi,
+                "w0": [w.cpu() for w in w0], "params": [p.detach().cpu() for p in net.parameters()]},
+               os.path.join(out_dir, f"rank{rank}.pt"))
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_two_ranks_dropout_streams_differ_and_match_oracle():
+    """Per-rank dropout streams are distinct, and the all-reduced gradient equals the fp64 oracle's full-batch
+    gradient under the concatenation of the two ranks' exported keep masks."""
+    import numpy as np
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import ltr_oracle as O
+    with tempfile.TemporaryDirectory() as d:
+        mp.spawn(_dropout_worker, args=(2, _free_port(), d), nprocs=2, join=True)
+        r0 = torch.load(os.path.join(d, "rank0.pt"), weights_only=True)
+        r1 = torch.load(os.path.join(d, "rank1.pt"), weights_only=True)
+    assert r0["m1"].shape == r1["m1"].shape
+    same = float((r0["m1"] == r1["m1"]).float().mean())
+    assert 0.45 < same < 0.55, same                           # independent Bernoulli(0.5) streams agree on ~half
+    assert torch.equal(r0["flat"], r1["flat"]) and r0["loss"] == r1["loss"]
+    X, y = _data()
+    keys = ["fc1.weight", "fc1.bias", "fc2.weight", "fc2.bias", "fc3.weight", "fc3.bias"]
+    p = {k: w.double().clone().requires_grad_(True) for k, w in zip(keys, r0["w0"])}
+    k1 = torch.cat([r0["m1"], r1["m1"]]).double().view(X.shape[0], X.shape[1], 136)
+    k2 = torch.cat([r0["m2"], r1["m2"]]).double().view(X.shape[0], X.shape[1], 136)
+    s = O.double_layer_forward(X.double(), p, k1, k2).squeeze(-1)
+    l = O.approx_ndcg(s, y.double())
+    l.backward()
+    assert abs(r0["loss"] - float(l)) < 1e-5 * abs(float(l))
+    ref = torch.cat([p[k].grad.reshape(-1) for k in keys]).numpy()
+    got = r0["flat"][:-1].numpy().astype(np.float64)
+    assert np.abs(got - ref).max() / np.abs(ref).max() < 1e-5
+
+
+@pytest.mark.timeout(900)
+def test_bench_self_launches_two_ranks():
+    """`python bench.py --gpus 2` with no launcher around it: the parent spawns the ranks itself and relays ONE
+    JSON line with n_gpus = 2 (gloo stands in for RCCL: two ranks share this box's one card)."""
+    import json
+    import subprocess
+    env = dict(os.environ, LTR_DIST_BACKEND="gloo")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--queries", "4096", "--batch", "1024",
+                        "--steps", "3", "--warmup", "1"], env=env, capture_output=True, text=True, timeout=800)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 3 and out["value"] > 0 and out["scaling"] == "weak"
+    assert out["config"]["batch_per_gpu"] == 1024

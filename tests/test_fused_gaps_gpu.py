@@ -1,0 +1,171 @@
+"""GPU: fused-path cases the round-1 suite did not reach (VERDICT r1 "What's weak" 9 / ADVICE):
+train-mode dropout at bench batch size against the fp64 oracle, fused lambdaLoss in train mode, fused approxNDCG
+with PARTIALLY padded slates, lambdaLoss k = 0 on every path, FusedRanker next to optimizer.zero_grad()."""
+import numpy as np
+import pytest
+import torch
+
+import ltr_oracle as O
+from conftest import ledger_record, relerr
+from test_scorer_gpu import LAMBDA_KW, _grads, _make, _oracle_step, assert_grads
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-5
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    import ltr_mi355x
+    ltr_mi355x.lib()
+    return torch.device("cuda:0")
+
+
+def _exported_masks(ranker_seed, n_docs, dev, B, S):
+    from ltr_mi355x import scorer
+    m1 = scorer.dropout_keep_mask(ranker_seed, 0, n_docs, 136, dev).cpu().float().view(B, S, 136)
+    m2 = scorer.dropout_keep_mask(ranker_seed, 1, n_docs, 136, dev).cpu().float().view(B, S, 136)
+    return m1, m2
+
+
+def test_bench_batch_train_mode_vs_fp64_oracle(dev):
+    """2 048 slates x 128 documents (262 144 documents accumulated per launch), DoubleLayerNet in TRAIN mode with the
+    counter-based dropout stream, whole batch against the fp64 oracle under the exported keep masks."""
+    from ltr_mi355x.scorer import FusedRanker
+    net, sd = _make("double", dev, 5)
+    net.train()
+    B, S = 2048, 128
+    gen = torch.Generator().manual_seed(77)
+    x = torch.randn(B, S, 136, generator=gen)
+    y = torch.multinomial(torch.tensor([0.52, 0.32, 0.13, 0.02, 0.01]), B * S, replacement=True, generator=gen).view(B, S).float()
+    seed = 0x0123456789ABCDEF
+    k1, k2 = _exported_masks(seed, B * S, dev, B, S)
+    rl, rg, _ = _oracle_step("double", sd, x, y, "approxNDCG", k1, k2)
+    _, rg32, _ = _oracle_step("double", sd, x, y, "approxNDCG", k1, k2, dtype=torch.float32)
+    ranker = FusedRanker(net, loss="approxNDCG")
+    out = ranker.step(x.to(dev), y.to(dev), seed=seed)
+    e = relerr(out.cpu().numpy(), rl)
+    ledger_record("bench-batch loss (2048 x 128, train mode)", e)
+    assert e < TOL
+    assert_grads(_grads(net), rg, ref32=rg32)
+
+
+@pytest.mark.parametrize("S", [32, 128])
+def test_fused_lambda_train_mode(S, dev):
+    from ltr_mi355x.scorer import FusedRanker
+    net, sd = _make("double", dev, 19)
+    net.train()
+    B = 9
+    gen = torch.Generator().manual_seed(300 + S)
+    x = torch.randn(B, S, 136, generator=gen)
+    y = torch.randint(0, 5, (B, S), generator=gen).float()
+    y[1, S - 7:] = -1.0
+    seed = 0xFEEDFACE12345678
+    k1, k2 = _exported_masks(seed, B * S, dev, B, S)
+    rl, rg, _ = _oracle_step("double", sd, x, y, "lambdaLoss", k1, k2)
+    _, rg32, _ = _oracle_step("double", sd, x, y, "lambdaLoss", k1, k2, dtype=torch.float32)
+    ranker = FusedRanker(net, loss="lambdaLoss", weighing_scheme="ndcgLoss2PP_scheme")
+    out = ranker.step(x.to(dev), y.to(dev), seed=seed)
+    assert relerr(out.cpu().numpy(), rl) < TOL
+    assert_grads(_grads(net), rg, ref32=rg32)
+
+
+@pytest.mark.parametrize("kind", ["triple", "double"])
+@pytest.mark.parametrize("S", [32, 64, 128])
+def test_fused_approx_partially_padded(kind, S, dev):
+    """Slates with a padded tail of varying length (1 document ... all but one), one all-padded slate, one
+    unpadded, inside the ONE-launch fused kernel."""
+    from ltr_mi355x.scorer import FusedRanker
+    net, sd = _make(kind, dev, 29)
+    net.eval()
+    B = 8
+    gen = torch.Generator().manual_seed(500 + S)
+    x = torch.randn(B, S, 136, generator=gen)
+    y = torch.randint(0, 5, (B, S), generator=gen).float()
+    for b, npad in enumerate([0, 1, 3, S // 2, S - 2, S - 1, S, 5]):
+        if npad:
+            y[b, S - npad:] = -1.0
+    y[7, ::3] = -1.0                                            # padding not confined to the tail
+    rl, rg, _ = _oracle_step(kind, sd, x, y, "approxNDCG")
+    _, rg32, _ = _oracle_step(kind, sd, x, y, "approxNDCG", dtype=torch.float32)
+    ranker = FusedRanker(net, loss="approxNDCG")
+    out = ranker.step(x.to(dev), y.to(dev))
+    assert relerr(out.cpu().numpy(), rl) < TOL
+    assert_grads(_grads(net), rg, ref32=rg32)
+
+
+@pytest.mark.parametrize("S", [128, 50])
+@pytest.mark.parametrize("red", ["sum", "mean"])
+def test_lambda_k0_keeps_nothing(S, red, dev):
+    """k = 0: `ndcg_at_k_mask[:0, :0]` is empty in the reference (lambdaL.py:29-30) -> loss 0 ("sum") / nan ("mean"),
+    zero gradient -- identically on the one-launch path (S = 128) and the three-launch path (S = 50)."""
+    from losses.lambdaL import lambdaLoss
+    from ltr_mi355x.scorer import FusedRanker
+    net, _ = _make("triple", dev, 3)
+    gen = torch.Generator().manual_seed(S)
+    x = torch.randn(4, S, 136, generator=gen).to(dev)
+    y = torch.randint(0, 5, (4, S), generator=gen).float().to(dev)
+    ranker = FusedRanker(net, loss="lambdaLoss", weighing_scheme="ndcgLoss2PP_scheme", k=0, reduction=red)
+    ranker.flat.fill_(7.0)
+    out = ranker.step(x, y)
+    assert float(ranker.flat_grad.abs().max()) == 0.0
+    assert (float(out) == 0.0) if red == "sum" else bool(torch.isnan(out))
+    s = torch.randn(4, S, device=dev, requires_grad=True)
+    l = lambdaLoss(s, y, weighing_scheme="ndcgLoss2PP_scheme", k=0, reduction=red)
+    assert (float(l) == 0.0) if red == "sum" else bool(torch.isnan(l))
+
+
+@pytest.mark.parametrize("order", ["zero_after_step", "zero_before_step", "module_zero_grad"])
+def test_fused_ranker_survives_zero_grad(order, dev):
+    """opt.zero_grad() defaults to set_to_none=True and drops the p.grad -> flat-buffer aliasing; the reference loop
+    calls it between the loss and backward (main_batch_execution.py:167).  Weights must move either way."""
+    from ltr_mi355x.scorer import FusedRanker
+    net, _ = _make("triple", dev, 8)
+    gen = torch.Generator().manual_seed(1)
+    x = torch.randn(6, 32, 136, generator=gen).to(dev)
+    y = torch.randint(0, 5, (6, 32), generator=gen).float().to(dev)
+    ranker = FusedRanker(net, loss="approxNDCG")
+    opt = torch.optim.SGD(net.parameters(), lr=0.5)
+    for it in range(3):
+        before = [p.detach().clone() for p in net.parameters()]
+        if order == "zero_before_step":
+            opt.zero_grad()
+            ranker.step(x, y)
+        elif order == "module_zero_grad":
+            net.zero_grad()
+            ranker.step(x, y)
+        else:
+            ranker.step(x, y)
+            # the reference's order: zero_grad sits between the loss and backward; with the fused step the gradients
+            # already exist here, so a set_to_none zero_grad only unbinds views -- step() re-binds them next time
+            if it > 0:
+                opt.zero_grad()
+                ranker.step(x, y)
+        for p in net.parameters():
+            assert p.grad is not None and p.grad.data_ptr() >= ranker.flat.data_ptr()
+        flat = torch.cat([p.grad.reshape(-1) for p in net.parameters()])
+        assert torch.equal(flat, ranker.flat_grad) and float(flat.abs().max()) > 0
+        opt.step()
+        moved = max(float((a - b.detach()).abs().max()) for a, b in zip(before, net.parameters()))
+        assert moved > 0.0, (order, it)
+
+
+def test_python_scheme_helpers(dev):
+    """The seven *_scheme functions of the module surface (string-dispatched in the reference, lambdaL.py:46,96-127):
+    device tensor expressions that must agree with the weights the kernels use -- checked through the oracle's
+    restatement of the same formulas on rank-ordered G, D."""
+    from losses import lambdaL
+    gen = torch.Generator().manual_seed(4)
+    B, S = 3, 12
+    G = torch.rand(B, S, generator=gen)
+    D = torch.log2(torch.arange(S, dtype=torch.float32) + 2.0)[None, :]
+    yt = torch.randint(0, 5, (B, S), generator=gen).float()
+    for name in ("ndcgLoss1_scheme", "ndcgLoss2_scheme", "lamdbaRank_scheme", "ndcgLoss2PP_scheme", "rankNet_scheme",
+                 "rankNetWeightedByGTDiff_scheme", "rankNetWeightedByGTDiffPowed_scheme"):
+        got = getattr(lambdaL, name)(G.to(dev), D.to(dev), 10.0, yt.to(dev))
+        ref = O.scheme_weights(name, G.double(), D[0].double(), 10.0, yt.double())
+        if isinstance(got, float):
+            assert got == 1.0 and float(ref) == 1.0
+            continue
+        assert got.device.type == "cuda"
+        assert relerr(torch.broadcast_to(got, (B, S, S)).cpu().numpy(), torch.broadcast_to(ref, (B, S, S)).numpy()) < 1e-6, name

@@ -5,7 +5,8 @@ import pytest
 import torch
 
 import ltr_oracle as O
-from conftest import golden, relerr
+from conftest import golden, ledger_record
+from conftest import relerr as _relerr
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-5
@@ -17,6 +18,12 @@ def dev():
     import ltr_mi355x
     ltr_mi355x.lib()
     return torch.device("cuda:0")
+
+
+def relerr(a, b, quantity="loss / scores / weights"):
+    e = _relerr(a, b)
+    ledger_record(quantity, e)
+    return e
 
 
 def T(a, dev):
@@ -43,9 +50,16 @@ def assert_grads(got, ref, tol=TOL, ref32=None):
     for k, v in got.items():
         r = np.asarray(ref[k], dtype=np.float64)
         d = float(np.abs(np.asarray(v, dtype=np.float64) - r).max())
-        noise = 0.0 if ref32 is None else 4.0 * float(np.abs(np.asarray(ref32[k], dtype=np.float64) - r).max())
-        assert d / max(top, 1e-30) < max(tol, noise / top), (k, "global", d / top, noise / top)
+        n1 = None if ref32 is None else float(np.abs(np.asarray(ref32[k], dtype=np.float64) - r).max())
+        noise = 0.0 if n1 is None else 4.0 * n1
         rmax = float(np.abs(r).max())
+        ledger_record(f"grad[{k}] / max|whole gradient|", d / max(top, 1e-30), None if n1 is None else n1 / top, tol)
+        if rmax >= 1e-3 * top:
+            ledger_record(f"grad[{k}] / max|tensor|", d / rmax, None if n1 is None else n1 / rmax, tol)
+        else:
+            ledger_record(f"grad[{k}] / max|tensor| (below 1e-3 of top gradient: not asserted)", d / max(rmax, 1e-30),
+                          None if n1 is None else n1 / max(rmax, 1e-30), tol, note="exact gradient ~0")
+        assert d / max(top, 1e-30) < max(tol, noise / top), (k, "global", d / top, noise / top)
         if rmax >= 1e-3 * top:
             assert d / rmax < max(tol, noise / rmax), (k, d / rmax, noise / rmax)
 
