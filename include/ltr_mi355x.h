@@ -92,6 +92,33 @@ int ltr_lambda_pairs_bwd(const float *scores, const float *labels, int B, int S,
                          float mu, float eps, float pad, int log_base, const float *grad_losses,
                          float *dscores, void *stream);
 
+/* ---- torch.sum(lambdaMask(..., return_losses=True), dim=1)        losses/riskLosses/riskLosses.py:72-83,192-203,302-310
+ * The only thing the risk losses take from the pair matrix is its column sums c[b, rj] = sum_ri losses[b, ri, rj]
+ * (rj = 0-based predicted rank): computed without materialising [B,S,S].  The backward takes d L / d c[B,S]. */
+int ltr_lambda_colsum_fwd(const float *scores, const float *labels, int B, int S, int scheme, int k, float sigma,
+                          float mu, float eps, float pad, int log_base, float *colsum, void *stream);
+int ltr_lambda_colsum_bwd(const float *scores, const float *labels, int B, int S, int scheme, int k, float sigma,
+                          float mu, float eps, float pad, int log_base, const float *grad_colsum, float *dscores,
+                          void *stream);
+
+/* ---- zRisk / geoRisk(mat, alpha, requires_grad, i)          losses/riskLosses/riskFunctions.py:4-22 / :25-33
+ * mat[Q][n_systems]: effectiveness of every system (column) on every query (row); col = the system under test
+ * (negative counts from the end, like the reference's i=-1).
+ *   LTR_RISK_Z  : value[0] = sum_q d_q (1 + alpha [d_q < 0]),  d_q = (mat[q,col] - e_q)/sqrt(e_q),
+ *                 e_q = (sum_q mat[q,col]) (sum_j mat[q,j]) / sum(mat)
+ *   LTR_RISK_GEO: value[0] = sqrt(mean_q mat[q,col] * Phi(zRisk / Q))
+ *   dmat[Q][n_systems] (NULL: forward only) = d value / d mat, analytic (the [d_q < 0] indicator carries none).
+ * One workgroup, fp64 accumulation, fixed summation order. */
+enum { LTR_RISK_Z = 0, LTR_RISK_GEO = 1 };
+int ltr_risk_fwd_bwd(const float *mat, int Q, int n_systems, int col, float alpha, int kind, float *value,
+                     float *dmat, void *stream);
+
+/* ---- tRisk tail                                            losses/riskLosses/riskLosses.py:278-291, :332-345
+ *   delta_q = (model[q] - baseline[q]) (1 + alpha [model[q] < baseline[q]]);  value[0] = mean(delta)/std(delta)
+ *   (unbiased std, torch.std);  dmodel / dbaseline [Q] (may be NULL) = d value / d model, d baseline. */
+int ltr_trisk_fwd_bwd(const float *model, const float *baseline, int Q, float alpha, float *value, float *dmodel,
+                      float *dbaseline, void *stream);
+
 /* ---- ordinalLoss(y_pred[B,S,n], y_true[B,S], n, padded_value_indicator)  losses/ordinal.py:27-53
  * n_docs = B*S documents, n ordinal probabilities each.  Targets 1[y >= k] are built with the default
  * indicator -1 (ordinal.py:39), then entries whose target == pad are masked (:41-45).

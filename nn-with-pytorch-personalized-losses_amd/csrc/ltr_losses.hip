@@ -191,10 +191,56 @@ lambda_pairs_fwd_kernel(const float *__restrict__ scores, const float *__restric
     }
 }
 
+// Column sums of the pair matrix, c[b, rj] = sum_ri losses[b, ri, rj] (what the risk losses take from
+// lambdaMask(return_losses=True): torch.sum(..., dim=1), riskLosses.py:72-83) WITHOUT materialising [B,S,S].
+template <int SCH>
+__global__ void __launch_bounds__(1024)
+lambda_colsum_fwd_kernel(const float *__restrict__ scores, const float *__restrict__ labels, int B, int S,
+                         int group, LambdaParams P, float pad, float *__restrict__ colsum) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int s_al = (S + 3) & ~3;
+    const int slate = blockIdx.x;
+    float *base = smem;
+    const LambdaLds L = lambda_carve(base, s_al);
+    int *dar = reinterpret_cast<int *>(base + kLambdaArrays * s_al);   // document at rank r
+    const SlateGroup g = make_group(S, group, base + (kLambdaArrays + 1) * s_al);
+    const size_t off = (size_t)slate * S;
+    for (int j = g.t; j < S; j += group) {
+        L.sc[j] = scores[off + j];
+        stage_label(labels[off + j], pad, L.yl[j], L.gn[j]);
+    }
+    __syncthreads();
+    lambda_prepare(g, L, P);
+    for (int j = g.t; j < S; j += group) dar[L.rk[j]] = j;
+    __syncthreads();
+    for (int rj = g.t; rj < S; rj += group) {
+        const int j = dar[rj];
+        const bool pj = L.gn[j] < 0.f;
+        const float sj = pj ? -INFINITY : L.sc[j];
+        const float Gj = fmaxf(L.gn[j], 0.f), ycj = fmaxf(L.yl[j], 0.f);
+        float acc = 0.f;
+        for (int ri = 0; ri < S; ++ri) {          // rank order: the order torch.sum(dim=1) walks the column in
+            const int i = dar[ri];
+            const bool pi = L.gn[i] < 0.f;
+            const float si = pi ? -INFINITY : L.sc[i];
+            float d = si - sj;
+            d = (d != d) ? 0.f : fminf(fmaxf(d, -1e8f), 1e8f);
+            float u, um;
+            sigmoid_pair(P.sigma * d, u, um);
+            const float Gi = fmaxf(L.gn[i], 0.f), yci = fmaxf(L.yl[i], 0.f);
+            float ell, dl;
+            lambda_pair_term(P, lambda_weight<SCH>(P, L.delta, L.rk[i], L.rk[j], L.invd[i], L.invd[j], L.w1[i], Gi, Gj, yci, ycj),
+                             u, um, ell, dl);
+            acc += ell;
+        }
+        colsum[off + rj] = acc;
+    }
+}
+
 template <int SCH>
 __global__ void __launch_bounds__(1024)
 lambda_pairs_bwd_kernel(const float *__restrict__ scores, const float *__restrict__ labels, int B, int S,
-                        int group, LambdaParams P, float pad, const float *__restrict__ gup,
+                        int group, LambdaParams P, float pad, const float *__restrict__ gup, int colsum,
                         float *__restrict__ dscores) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int s_al = (S + 3) & ~3;
@@ -209,7 +255,8 @@ lambda_pairs_bwd_kernel(const float *__restrict__ scores, const float *__restric
     }
     __syncthreads();
     lambda_prepare(g, L, P);
-    const float *G = gup + (size_t)slate * S * S;
+    // colsum != 0: the upstream gradient is that of  c[b, rj] = sum_ri losses[b, ri, rj]  -> G[ri, rj] = gup[b, rj]
+    const float *G = gup + (size_t)slate * S * (colsum ? 1 : S);
     for (int i0 = 0; i0 < S; i0 += g.sp) {
         const int i = i0 + g.ri;
         const bool row = i < S;
@@ -232,7 +279,9 @@ lambda_pairs_bwd_kernel(const float *__restrict__ scores, const float *__restric
                                  u, um, ell, dl_ij);
                 lambda_pair_term(P, lambda_weight<SCH>(P, L.delta, rj, ri, L.invd[j], L.invd[i], L.w1[j], Gj, Gi, ycj, yci),
                                  um, u, ell, dl_ji);
-                gr += G[(size_t)ri * S + rj] * dl_ij - G[(size_t)rj * S + ri] * dl_ji;
+                const float g_ij = colsum ? G[rj] : G[(size_t)ri * S + rj];
+                const float g_ji = colsum ? G[ri] : G[(size_t)rj * S + ri];
+                gr += g_ij * dl_ij - g_ji * dl_ji;
             }
         }
         const float tot = row_reduce(g, gr);
@@ -457,7 +506,43 @@ int ltr_lambda_pairs_bwd(const float *scores, const float *labels, int B, int S,
 #define CALL(SCH)                                                                                                 \
     if (int rc = allow_lds(lambda_pairs_bwd_kernel<SCH>, lds)) return rc;                                         \
     hipLaunchKernelGGL(lambda_pairs_bwd_kernel<SCH>, dim3(B), dim3(group), lds, (hipStream_t)stream, scores,      \
-                       labels, B, S, group, P, pad, grad_losses, dscores)
+                       labels, B, S, group, P, pad, grad_losses, 0, dscores)
+    LTR_DISPATCH_SCHEME(scheme, CALL)
+#undef CALL
+    return launch_status();
+}
+
+int ltr_lambda_colsum_fwd(const float *scores, const float *labels, int B, int S, int scheme, int k, float sigma,
+                          float mu, float eps, float pad, int log_base, float *colsum, void *stream) {
+    if (int rc = check_slates(scores, labels, colsum, B, S)) return rc;
+    LambdaParams P;
+    if (int rc = make_lambda_params(scheme, k, sigma, mu, eps, log_base, &P)) return rc;
+    if (B == 0) return LTR_OK;
+    const int group = next_pow2(S) < 64 ? 64 : (next_pow2(S) > 1024 ? 1024 : next_pow2(S));
+    const size_t lds = (size_t)((kLambdaArrays + 1) * ((S + 3) & ~3) + group + 32) * sizeof(float);
+#define CALL(SCH)                                                                                                 \
+    if (int rc = allow_lds(lambda_colsum_fwd_kernel<SCH>, lds)) return rc;                                        \
+    hipLaunchKernelGGL(lambda_colsum_fwd_kernel<SCH>, dim3(B), dim3(group), lds, (hipStream_t)stream, scores,     \
+                       labels, B, S, group, P, pad, colsum)
+    LTR_DISPATCH_SCHEME(scheme, CALL)
+#undef CALL
+    return launch_status();
+}
+
+int ltr_lambda_colsum_bwd(const float *scores, const float *labels, int B, int S, int scheme, int k, float sigma,
+                          float mu, float eps, float pad, int log_base, const float *grad_colsum, float *dscores,
+                          void *stream) {
+    if (int rc = check_slates(scores, labels, dscores, B, S)) return rc;
+    if (!grad_colsum) return LTR_ERR_NULL;
+    LambdaParams P;
+    if (int rc = make_lambda_params(scheme, k, sigma, mu, eps, log_base, &P)) return rc;
+    if (B == 0) return LTR_OK;
+    const int group = pick_group(S) < 256 ? 256 : pick_group(S);
+    const size_t lds = (size_t)(kLambdaArrays * ((S + 3) & ~3) + group + 32) * sizeof(float);
+#define CALL(SCH)                                                                                                 \
+    if (int rc = allow_lds(lambda_pairs_bwd_kernel<SCH>, lds)) return rc;                                         \
+    hipLaunchKernelGGL(lambda_pairs_bwd_kernel<SCH>, dim3(B), dim3(group), lds, (hipStream_t)stream, scores,      \
+                       labels, B, S, group, P, pad, grad_colsum, 1, dscores)
     LTR_DISPATCH_SCHEME(scheme, CALL)
 #undef CALL
     return launch_status();

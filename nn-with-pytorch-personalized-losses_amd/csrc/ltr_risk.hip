@@ -1,0 +1,164 @@
+// ltr_risk.hip -- risk-sensitive evaluation functions on a [queries x systems] effectiveness matrix (gfx950).
+//
+// Replaces, behind the reference's Python surface:
+//   losses/riskLosses/riskFunctions.py:4-22   zRisk(mat, alpha, requires_grad, i)
+//   losses/riskLosses/riskFunctions.py:25-33  geoRisk(mat, alpha, requires_grad, i)
+//   losses/riskLosses/riskLosses.py:247-291   the tRisk tail (mean / std of the alpha-weighted deltas)
+// The matrix is tiny next to the slate tensors (Q x <= ~10 systems): these are latency-bound reductions, so
+// each runs as ONE workgroup that sweeps the matrix three times (column/row sums -> standardised residuals ->
+// gradient) with fp64 accumulators and fixed-order cross-wave sums (bit-reproducible).  Forward value and the
+// analytic gradient w.r.t. every matrix entry come out of the same launch.
+#include "../../include/ltr_mi355x.h"
+#include "ltr_device.h"
+#include <math.h>
+
+using namespace ltr;
+
+namespace {
+
+constexpr int kRiskThreads = 1024;
+
+__device__ __forceinline__ double wave_allsum_f64(double v) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, LTR_WAVE);
+    return v;   // butterfly: every lane holds the same bits
+}
+
+// sum over the block; every thread gets the total (fixed order: lanes by butterfly, waves sequentially)
+__device__ __forceinline__ double block_sum_f64(double v, double *red) {
+    v = wave_allsum_f64(v);
+    __syncthreads();
+    if ((threadIdx.x & (LTR_WAVE - 1)) == 0) red[threadIdx.x / LTR_WAVE] = v;
+    __syncthreads();
+    double s = 0.0;
+    for (int w = 0; w < kRiskThreads / LTR_WAVE; ++w) s += red[w];
+    return s;
+}
+
+// zRisk:  si = sum_q mat[q,i];  t_q = sum_j mat[q,j];  n = sum_q t_q;  e_q = si t_q / n;
+//         d_q = (mat[q,i] - e_q) / sqrt(e_q);  Z = sum_q d_q (1 + alpha [d_q < 0])                 (:5-22)
+// geoRisk: sqrt((si / Q) * Phi(Z / Q)), Phi = standard normal cdf                                   (:26-33)
+// dmat (optional): d value / d mat[q,j] (closed form; the indicator [d_q < 0] carries no gradient, like the
+// reference's boolean mask).
+__global__ void __launch_bounds__(kRiskThreads)
+risk_kernel(const float *__restrict__ mat, int Q, int n, int col, float alpha, int geo, float *__restrict__ value,
+            float *__restrict__ dmat) {
+    __shared__ double red[kRiskThreads / LTR_WAVE];
+    const int tid = threadIdx.x;
+    double s_i = 0.0, s_n = 0.0;
+    for (int q = tid; q < Q; q += kRiskThreads) {
+        const float *row = mat + (size_t)q * n;
+        double t = 0.0;
+        for (int j = 0; j < n; ++j) t += (double)row[j];
+        s_n += t;
+        s_i += (double)row[col];
+    }
+    const double si = block_sum_f64(s_i, red);
+    const double nn = block_sum_f64(s_n, red);
+    double z_acc = 0.0, t1_acc = 0.0;
+    for (int q = tid; q < Q; q += kRiskThreads) {
+        const float *row = mat + (size_t)q * n;
+        double t = 0.0;
+        for (int j = 0; j < n; ++j) t += (double)row[j];
+        const double x = (double)row[col];
+        const double e = si * (t / nn);
+        const double d = (x - e) / sqrt(e);
+        const double c = d < 0.0 ? 1.0 + (double)alpha : 1.0;
+        z_acc += c * d;
+        const double A = c * (-0.5 * (x + e) / (e * sqrt(e)));     // c_q * d d_q / d e_q
+        t1_acc += A * t;
+    }
+    const double Z = block_sum_f64(z_acc, red);
+    const double T1 = block_sum_f64(t1_acc, red) / nn;              // sum_r A_r t_r / n
+    double val = Z, dZ = 1.0, dSi = 0.0;
+    if (geo) {
+        const double v = Z / (double)Q;
+        const double Phi = 0.5 * erfc(-v * 0.70710678118654752440);
+        const double phi = 0.39894228040143267794 * exp(-0.5 * v * v);
+        const double M = si / (double)Q;
+        val = sqrt(M * Phi);
+        dZ = 0.5 / val * M * phi / (double)Q;
+        dSi = 0.5 / val * Phi / (double)Q;
+    }
+    if (tid == 0) value[0] = (float)val;
+    if (!dmat) return;
+    for (int q = tid; q < Q; q += kRiskThreads) {
+        const float *row = mat + (size_t)q * n;
+        double t = 0.0;
+        for (int j = 0; j < n; ++j) t += (double)row[j];
+        const double x = (double)row[col];
+        const double e = si * (t / nn);
+        const double rs = 1.0 / sqrt(e);
+        const double d = (x - e) * rs;
+        const double c = d < 0.0 ? 1.0 + (double)alpha : 1.0;
+        const double A = c * (-0.5 * (x + e) * rs / e);
+        const double common = A * si / nn - si * T1 / nn;          // via t_q and via n
+        const double own = c * rs + T1;                             // via mat[q,i] itself and via si
+        for (int j = 0; j < n; ++j) {
+            double gz = common + (j == col ? own : 0.0);
+            dmat[(size_t)q * n + j] = (float)(dZ * gz + (j == col ? dSi : 0.0));
+        }
+    }
+}
+
+// tRisk tail: delta_q = (a_q - b_q)(1 + alpha [a_q < b_q]);  value = mean(delta) / std(delta)  (unbiased std)
+// da / db (optional): d value / d a_q, d value / d b_q.                       riskLosses.py:278-291 / :332-345
+__global__ void __launch_bounds__(kRiskThreads)
+trisk_kernel(const float *__restrict__ a, const float *__restrict__ b, int Q, float alpha, float *__restrict__ value,
+             float *__restrict__ da, float *__restrict__ db) {
+    __shared__ double red[kRiskThreads / LTR_WAVE];
+    const int tid = threadIdx.x;
+    double s = 0.0;
+    for (int q = tid; q < Q; q += kRiskThreads) {
+        const double x = (double)a[q] - (double)b[q];
+        s += x * (a[q] < b[q] ? 1.0 + (double)alpha : 1.0);
+    }
+    const double mu = block_sum_f64(s, red) / (double)Q;
+    double v = 0.0;
+    for (int q = tid; q < Q; q += kRiskThreads) {
+        const double x = ((double)a[q] - (double)b[q]) * (a[q] < b[q] ? 1.0 + (double)alpha : 1.0);
+        v += (x - mu) * (x - mu);
+    }
+    const double var = block_sum_f64(v, red) / (double)(Q - 1);
+    const double se = sqrt(var);
+    if (tid == 0) value[0] = (float)(mu / se);
+    if (!da && !db) return;
+    for (int q = tid; q < Q; q += kRiskThreads) {
+        const double c = a[q] < b[q] ? 1.0 + (double)alpha : 1.0;
+        const double x = ((double)a[q] - (double)b[q]) * c;
+        const double g = (1.0 / ((double)Q * se) - mu * (x - mu) / ((double)(Q - 1) * se * var)) * c;
+        if (da) da[q] = (float)g;
+        if (db) db[q] = (float)(-g);
+    }
+}
+
+inline int status() {
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? LTR_OK : (int)e;
+}
+
+}  // namespace
+
+extern "C" {
+
+int ltr_risk_fwd_bwd(const float *mat, int Q, int n_systems, int col, float alpha, int kind, float *value,
+                     float *dmat, void *stream) {
+    if (!mat || !value) return LTR_ERR_NULL;
+    if (Q < 1 || n_systems < 1 || n_systems > 4096) return LTR_ERR_SHAPE;
+    if (col < 0) col += n_systems;                       /* i = -1: the last system, as Python indexes */
+    if (col < 0 || col >= n_systems || (kind != LTR_RISK_Z && kind != LTR_RISK_GEO)) return LTR_ERR_PARAM;
+    hipLaunchKernelGGL(risk_kernel, dim3(1), dim3(kRiskThreads), 0, (hipStream_t)stream, mat, Q, n_systems, col, alpha,
+                       kind == LTR_RISK_GEO ? 1 : 0, value, dmat);
+    return status();
+}
+
+int ltr_trisk_fwd_bwd(const float *model, const float *baseline, int Q, float alpha, float *value, float *dmodel,
+                      float *dbaseline, void *stream) {
+    if (!model || !baseline || !value) return LTR_ERR_NULL;
+    if (Q < 1) return LTR_ERR_SHAPE;
+    hipLaunchKernelGGL(trisk_kernel, dim3(1), dim3(kRiskThreads), 0, (hipStream_t)stream, model, baseline, Q, alpha, value,
+                       dmodel, dbaseline);
+    return status();
+}
+
+}  // extern "C"

@@ -1,0 +1,175 @@
+"""MI355X drop-in for losses/riskLosses/riskLosses.py of the reference: the six risk-sensitive listwise losses
+(geoRisk / zRisk / tRisk  x  Listnet / Lambda, :8, :63, :128, :183, :247, :294) with the reference's signatures,
+defaults, shapes and quirks.
+
+Each loss builds a [queries, systems] effectiveness matrix -- column 0 the model, then the baseline rankers,
+optionally the ideal ranking -- from row-softmaxed labels / predictions / baseline scores, and hands it to a risk
+function.  On the MI355X: the pair-matrix column sums of the Lambda variants come from `ltr_lambda_colsum_*`
+(no [B,S,S] tensor is ever written), the risk reductions from `ltr_risk_fwd_bwd` / `ltr_trisk_fwd_bwd`
+(forward + analytic gradient per launch); the [B,S]-sized glue in between (softmax, squares, cosine) is plain
+device tensor algebra.  Device tensors only.
+"""
+import torch
+import torch.nn.functional as F
+
+from losses.riskLosses.riskFunctions import geoRisk, zRisk
+from ltr_mi355x import risk as _risk
+from ltr_mi355x.functional import require_device
+
+
+def _probs(y_predicted, y_true, y_baselines):
+    require_device(y_predicted, y_true)
+    pb = None if y_baselines is None else torch.squeeze(F.softmax(y_baselines, dim=1))     # :10-11
+    return torch.squeeze(F.softmax(y_true, dim=1)), torch.squeeze(F.softmax(y_predicted, dim=1)), pb
+
+
+def _cos(a, b):
+    return torch.nn.CosineSimilarity(dim=1)(a, b)
+
+
+def _unbound():
+    # the reference leaves `mat` unassigned for transformations it does not implement (e.g. :66-86 has no
+    # listnet_transformation == 3 branch) and dies on its first use; same exception type and message
+    raise UnboundLocalError("local variable 'mat' referenced before assignment")
+
+
+def _listnet_mat(p_true, p_pred, p_base, lt, add_ideal):
+    """Queries x systems matrix of the Listnet-type losses (:16-49, :136-169)."""
+    if lt == 1:
+        t2 = p_true * p_true
+        eff = lambda p: (p_true * p - t2) ** 2                                              # noqa: E731
+    elif lt == 2:
+        eff = lambda p: _cos(p_true, p)                                                     # noqa: E731
+    elif lt == 3:
+        t2 = torch.sum(p_true * p_true, dim=1)
+        eff = lambda p: (torch.sum(p_true * p, dim=1) - t2) ** 2                            # noqa: E731
+    else:
+        _unbound()
+    mat = [eff(p_pred)]
+    if p_base is not None:
+        mat += [eff(p_base[:, :, i]) for i in range(p_base.shape[2])]
+    if add_ideal == 2:
+        mat.append(eff(p_true))
+    mat = torch.stack(mat)
+    if lt == 1:
+        mat = torch.sum(mat, dim=2)
+    mat = mat.t()
+    if lt == 1 or lt == 3:       # larger distance = worse: flip so that larger = better (:47-49)
+        mat = -mat + torch.max(mat)
+    return mat
+
+
+def _lambda_mat(p_true, p_pred, p_base, lt, add_ideal, scheme, ideal_is_ones):
+    """Queries x systems matrix of the Lambda-type losses (:71-117, :191-236): effectiveness from the column sums of
+    lambdaMask(p, p_true, weighing_scheme, return_losses=True)."""
+    if lt not in (1, 2):
+        _unbound()
+    cs = lambda p: _risk.lambda_colsum(p, p_true, scheme)                                   # noqa: E731
+    tt = cs(p_true)
+    eff = (lambda c: (c - tt) ** 2) if lt == 1 else (lambda c: _cos(tt, c))                 # noqa: E731
+    mat = [eff(cs(p_pred))]
+    if p_base is not None:
+        mat += [eff(cs(p_base[:, :, i].contiguous())) for i in range(p_base.shape[2])]
+    if add_ideal == 2:
+        if lt == 2 and ideal_is_ones:
+            mat.append(torch.ones(tt.shape[0], dtype=torch.float, device=tt.device))        # :106
+        else:
+            mat.append(eff(tt))
+    mat = torch.stack(mat)
+    if lt == 1:
+        mat = torch.sum(mat, dim=2)
+    mat = mat.t()
+    if lt == 1:
+        mat = -mat + torch.max(mat)
+    return mat
+
+
+def _factor(negative, like):
+    return torch.tensor([negative], requires_grad=True, dtype=torch.float, device=like.device)
+
+
+def _by_strategy(risk, mat, alpha, return_strategy, factor):
+    if return_strategy == 1:
+        return factor * risk(mat, alpha, requires_grad=True)
+    elif return_strategy == 2:
+        return factor * (risk(mat, alpha, requires_grad=True, i=-1) - risk(mat, alpha, requires_grad=True))
+    elif return_strategy == 3:
+        return factor * ((risk(mat, alpha, requires_grad=True, i=-1) - risk(mat, alpha, requires_grad=True)) ** 2)
+    return None
+
+
+def geoRiskListnetLoss(y_predicted, y_true, y_baselines=None, alpha=5, listnet_transformation=1, return_strategy=1,
+                       negative=1, add_ideal_ranking_to_mat=1):
+    p_true, p_pred, p_base = _probs(y_predicted, y_true, y_baselines)
+    mat = _listnet_mat(p_true, p_pred, p_base, listnet_transformation, add_ideal_ranking_to_mat)
+    return _by_strategy(geoRisk, mat, alpha, return_strategy, _factor(negative, mat))
+
+
+def geoRiskLambdaLoss(y_predicted, y_true, y_baselines=None, alpha=5, listnet_transformation=1, return_strategy=1,
+                      negative=1, add_ideal_ranking_to_mat=1, weighing_scheme="ndcgLoss2PP_scheme"):
+    p_true, p_pred, p_base = _probs(y_predicted, y_true, y_baselines)
+    mat = _lambda_mat(p_true, p_pred, p_base, listnet_transformation, add_ideal_ranking_to_mat, weighing_scheme, True)
+    return _by_strategy(geoRisk, mat, alpha, return_strategy, _factor(negative, mat))
+
+
+def zRiskListnetLoss(y_predicted, y_true, y_baselines=None, alpha=5, listnet_transformation=1, return_strategy=1,
+                     negative=1, add_ideal_ranking_to_mat=1):
+    p_true, p_pred, p_base = _probs(y_predicted, y_true, y_baselines)
+    mat = _listnet_mat(p_true, p_pred, p_base, listnet_transformation, add_ideal_ranking_to_mat)
+    factor = _factor(negative, mat)
+    # the reference's operator precedence (:176-178): `factor` multiplies only the first term of strategy 2 and
+    # the squared difference of strategy 3
+    if return_strategy == 1:
+        return factor * zRisk(mat, alpha, requires_grad=True)
+    elif return_strategy == 2:
+        return factor * zRisk(mat, alpha, requires_grad=True, i=-1) - zRisk(mat, alpha, requires_grad=True)
+    elif return_strategy == 3:
+        return factor * (zRisk(mat, alpha, requires_grad=True, i=-1) - zRisk(mat, alpha, requires_grad=True)) ** 2
+    return None
+
+
+def zRiskLambdaLoss(y_predicted, y_true, y_baselines=None, alpha=5, listnet_transformation=1, return_strategy=1,
+                    negative=1, add_ideal_ranking_to_mat=1, weighing_scheme="ndcgLoss2PP_scheme"):
+    p_true, p_pred, p_base = _probs(y_predicted, y_true, y_baselines)
+    mat = _lambda_mat(p_true, p_pred, p_base, listnet_transformation, add_ideal_ranking_to_mat, weighing_scheme, False)
+    return _by_strategy(zRisk, mat, alpha, return_strategy, _factor(negative, mat))
+
+
+def _trisk_tail(mat, lt, alpha, negative):
+    """:269-291: flip (transformation 1 only), alpha-weight the per-query deltas against the baseline, mean / std."""
+    if lt == 1:
+        mat = torch.sum(mat, dim=2)
+        mat = -mat + torch.max(mat)
+    return _factor(negative, mat) * _risk.TRisk.apply(mat[0], mat[1], alpha)
+
+
+def tRiskListnetLoss(y_predicted, y_true, y_baselines, alpha=5, listnet_transformation=1, negative=1):
+    p_true, p_pred, p_base = _probs(y_predicted, y_true, y_baselines)
+    q_true, q_pred, q_base = p_true * p_true, p_true * p_pred, p_true * p_base
+    if listnet_transformation == 1:
+        mat = [(q_pred - q_true) ** 2, (q_base - q_true) ** 2]
+    elif listnet_transformation == 2:
+        mat = [_cos(q_true, q_pred), _cos(q_true, q_base)]
+    elif listnet_transformation == 3:
+        t2 = torch.sum(q_true, dim=1)
+        mat = [(torch.sum(q_pred, dim=1) - t2) ** 2, (torch.sum(q_base, dim=1) - t2) ** 2]
+    else:
+        mat = []                       # torch.stack([]) raises, as in the reference (:269)
+    return _trisk_tail(torch.stack(mat), listnet_transformation, alpha, negative)
+
+
+def tRiskLambdaLoss(y_predicted, y_true, y_baselines, alpha=5, listnet_transformation=1, negative=1,
+                    weighing_scheme="ndcgLoss2PP_scheme"):
+    p_true, p_pred, p_base = _probs(y_predicted, y_true, y_baselines)
+    cs = lambda p: _risk.lambda_colsum(p, p_true, weighing_scheme)                          # noqa: E731
+    q_true, q_pred, q_base = cs(p_true), cs(p_pred), cs(p_base)
+    if listnet_transformation == 1:
+        mat = [(q_pred - q_true) ** 2, (q_base - q_true) ** 2]
+    elif listnet_transformation == 2:
+        mat = [_cos(q_true, q_pred), _cos(q_true, q_base)]
+    elif listnet_transformation == 3:
+        t2 = torch.sum(q_true, dim=1)
+        mat = [(torch.sum(q_pred, dim=1) - t2) ** 2, (torch.sum(q_base, dim=1) - t2) ** 2]
+    else:
+        mat = []
+    return _trisk_tail(torch.stack(mat), listnet_transformation, alpha, negative)

@@ -33,6 +33,11 @@ _PROTOTYPES = {
                                      P, P, P, P]),
     "ltr_lambda_pairs_bwd": (c_int, [P, P, c_int, c_int, c_int, c_int, c_float, c_float, c_float, c_float, c_int,
                                      P, P, P]),
+    "ltr_lambda_colsum_fwd": (c_int, [P, P, c_int, c_int, c_int, c_int, c_float, c_float, c_float, c_float, c_int, P, P]),
+    "ltr_lambda_colsum_bwd": (c_int, [P, P, c_int, c_int, c_int, c_int, c_float, c_float, c_float, c_float, c_int,
+                                      P, P, P]),
+    "ltr_risk_fwd_bwd": (c_int, [P, c_int, c_int, c_int, c_float, c_int, P, P, P]),
+    "ltr_trisk_fwd_bwd": (c_int, [P, P, c_int, c_float, P, P, P, P]),
     "ltr_ordinal_num_blocks": (c_int64, [c_int64]),
     "ltr_ordinal_fwd_bwd": (c_int, [P, P, c_int64, c_int, c_float, P, P, P, P]),
 }

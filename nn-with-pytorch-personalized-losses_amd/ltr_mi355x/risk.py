@@ -1,0 +1,110 @@
+"""Host side of the risk-sensitive losses: autograd Functions over the HIP kernels of
+csrc/ltr_risk.hip (zRisk / geoRisk / tRisk reductions on a [queries x systems] matrix) and the pair-matrix
+column sums of csrc/ltr_losses.hip (ltr_lambda_colsum_*), used by losses/riskLosses/*.py.
+Device tensors only; no CPU fallback."""
+import torch
+
+from ._lib import check, lib
+from .functional import _f32, _lambda_args, _ptr, _stream, require_device
+
+RISK_Z, RISK_GEO = 0, 1
+
+
+class RiskEval(torch.autograd.Function):
+    """zRisk / geoRisk of column `col` of mat [Q, n_systems] (riskFunctions.py:4-33) -> ltr_risk_fwd_bwd.
+    Forward value and d value / d mat come out of one launch."""
+
+    @staticmethod
+    def forward(ctx, mat, alpha, col, kind):
+        if mat.dim() != 2:
+            raise ValueError(f"risk functions take a [queries, systems] matrix, got {tuple(mat.shape)}")
+        Q, n = mat.shape
+        ctx.in_dtype = mat.dtype
+        with torch.cuda.device(mat.device):
+            m = _f32(mat)
+            out = torch.empty(1, dtype=torch.float32, device=mat.device)
+            dmat = torch.empty_like(m) if ctx.needs_input_grad[0] else None
+            check(lib().ltr_risk_fwd_bwd(_ptr(m), Q, n, int(col), float(alpha), int(kind), _ptr(out), _ptr(dmat), _stream()),
+                  "ltr_risk_fwd_bwd")
+        ctx.save_for_backward(dmat)
+        return out
+
+    @staticmethod
+    def backward(ctx, go):
+        (dmat,) = ctx.saved_tensors
+        return (dmat * go.to(torch.float32)).to(ctx.in_dtype), None, None, None
+
+
+class TRisk(torch.autograd.Function):
+    """mean / std of the alpha-weighted per-query deltas (riskLosses.py:278-291) -> ltr_trisk_fwd_bwd."""
+
+    @staticmethod
+    def forward(ctx, model, baseline, alpha):
+        if model.dim() != 1 or model.shape != baseline.shape:
+            raise ValueError(f"tRisk takes two [queries] vectors, got {tuple(model.shape)} / {tuple(baseline.shape)}")
+        ctx.dtypes = (model.dtype, baseline.dtype)
+        with torch.cuda.device(model.device):
+            a, b = _f32(model), _f32(baseline)
+            out = torch.empty(1, dtype=torch.float32, device=a.device)
+            da = torch.empty_like(a) if ctx.needs_input_grad[0] else None
+            db = torch.empty_like(b) if ctx.needs_input_grad[1] else None
+            check(lib().ltr_trisk_fwd_bwd(_ptr(a), _ptr(b), a.numel(), float(alpha), _ptr(out), _ptr(da), _ptr(db), _stream()),
+                  "ltr_trisk_fwd_bwd")
+        ctx.save_for_backward(da, db)
+        return out
+
+    @staticmethod
+    def backward(ctx, go):
+        da, db = ctx.saved_tensors
+        g = go.to(torch.float32)
+        return (None if da is None else (da * g).to(ctx.dtypes[0]), None if db is None else (db * g).to(ctx.dtypes[1]), None)
+
+
+class LambdaColsum(torch.autograd.Function):
+    """torch.sum(lambdaMask(y_pred, y_true, ..., return_losses=True), dim=1) without the [B,S,S] tensor
+    (riskLosses.py:72-83) -> ltr_lambda_colsum_{fwd,bwd}.  Result [B, S] indexed by predicted rank."""
+
+    @staticmethod
+    def forward(ctx, y_pred, y_true, eps, pad, scheme, k, sigma, mu, reduction_log):
+        args = _lambda_args(eps, pad, scheme, k, sigma, mu, reduction_log)
+        if y_pred.dim() != 2 or y_pred.shape != y_true.shape:
+            raise ValueError(f"expected y_pred / y_true [batch_size, slate_length], got {tuple(y_pred.shape)} / {tuple(y_true.shape)}")
+        B, S = y_pred.shape
+        ctx.in_dtype = y_pred.dtype
+        largs = (args[0], max(args[1], 0)) + args[2:]
+        with torch.cuda.device(y_pred.device):
+            s, y = _f32(y_pred), _f32(y_true)
+            out = torch.empty((B, S), dtype=torch.float32, device=s.device)
+            if B > 0:
+                check(lib().ltr_lambda_colsum_fwd(_ptr(s), _ptr(y), B, S, *largs, _ptr(out), _stream()), "ltr_lambda_colsum_fwd")
+        ctx.save_for_backward(s, y)
+        ctx.largs = largs
+        return out.to(torch.result_type(y_pred, y_true))
+
+    @staticmethod
+    def backward(ctx, g):
+        s, y = ctx.saved_tensors
+        B, S = s.shape
+        ds = torch.zeros_like(s)
+        if B > 0:
+            with torch.cuda.device(s.device):
+                gg = g.to(torch.float32).contiguous()
+                check(lib().ltr_lambda_colsum_bwd(_ptr(s), _ptr(y), B, S, *ctx.largs, _ptr(gg), _ptr(ds), _stream()),
+                      "ltr_lambda_colsum_bwd")
+        return (ds.to(ctx.in_dtype),) + (None,) * 8
+
+
+def z_risk(mat, alpha, i=0):
+    require_device(mat)
+    return RiskEval.apply(mat, alpha, i, RISK_Z)
+
+
+def geo_risk(mat, alpha, i=0):
+    require_device(mat)
+    return RiskEval.apply(mat, alpha, i, RISK_GEO)
+
+
+def lambda_colsum(y_pred, y_true, weighing_scheme, eps=1e-10, padded_value_indicator=-1, k=None, sigma=1., mu=10.,
+                  reduction_log="binary"):
+    require_device(y_pred, y_true)
+    return LambdaColsum.apply(y_pred, y_true, eps, padded_value_indicator, weighing_scheme, k, sigma, mu, reduction_log)

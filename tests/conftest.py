@@ -28,8 +28,7 @@ class Golden:
     """One fixture group: manifest cases + lazily loaded arrays (numpy.load, allow_pickle=False)."""
 
     def __init__(self, group):
-        with open(os.path.join(GOLDEN, "manifest.json")) as f:
-            self.cases = json.load(f)[group]
+        self.cases = _manifest()[group]
         self.npz = np.load(os.path.join(GOLDEN, f"{group}.npz"), allow_pickle=False)
 
     def arr(self, case, name):
@@ -48,9 +47,17 @@ def golden(group):
     return _cache[group]
 
 
+def _manifest():
+    """manifest.json (round 1: approx / listnet / lambda / ordinal / scorers) + manifest_r2.json (risk / metrics)."""
+    out = {}
+    for name in ("manifest.json", "manifest_r2.json"):
+        with open(os.path.join(GOLDEN, name)) as f:
+            out.update({k: v for k, v in json.load(f).items() if not k.startswith("_")})
+    return out
+
+
 def golden_cases(group):
-    with open(os.path.join(GOLDEN, "manifest.json")) as f:
-        return json.load(f)[group]
+    return _manifest()[group]
 
 
 def relerr(a, b):

@@ -1,0 +1,148 @@
+"""GPU parity tests for the risk-sensitive losses: zRisk / geoRisk kernels, the pair-matrix
+column sums, the tRisk tail and the six losses through the reference's own import surface
+(losses.riskLosses.riskFunctions / riskLosses) against the reference's golden vectors and the fp64 oracle.
+Bar: max|delta| / max|ref| <= max(1e-5, 4 x the reference's own fp32-vs-fp64 deviation on that case)."""
+import numpy as np
+import pytest
+import torch
+
+import ltr_oracle as O
+import ltr_risk_oracle as RO
+from conftest import golden, golden_cases, ledger_record, relerr
+from test_oracle_golden_r2 import oracle_risk_loss
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-5
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    import ltr_mi355x
+    ltr_mi355x.lib()
+    return torch.device("cuda:0")
+
+
+def T(a, dev):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+
+def test_georisk_known_answer(dev):
+    """The reference's only KAT: tests/georiskTorchTest.py:5-12 prints geoRisk(5x8 matrix, 3) ~ 0.31438308416523303."""
+    from losses.riskLosses.riskFunctions import geoRisk
+    g = golden("risk")
+    case = next(c for c in g.cases if c["id"] == "geoRisk_kat_i0")
+    u = geoRisk(T(g.arr(case, "mat"), dev), 3)
+    assert u.shape == (1,) and u.device.type == "cuda"
+    assert abs(float(u) - 0.31438308416523303) < 1e-6
+
+
+@pytest.mark.parametrize("case", [c for c in golden_cases("risk") if c["kind"] == "function"], ids=lambda c: c["id"])
+def test_risk_functions_golden(case, dev):
+    from losses.riskLosses.riskFunctions import geoRisk, zRisk
+    g = golden("risk")
+    fn = geoRisk if case["fn"] == "geoRisk" else zRisk
+    m = T(g.arr(case, "mat"), dev).requires_grad_(True)
+    out = fn(m, case["alpha"], requires_grad=True, i=case["i"])
+    assert out.shape == ((1,) if case["fn"] == "geoRisk" else ())
+    out.sum().backward()
+    noise = max(relerr(g.arr(case, "value"), g.arr(case, "value64")), relerr(g.arr(case, "grad"), g.arr(case, "grad64")))
+    ev, eg = relerr(out.detach().cpu().numpy(), g.arr(case, "value64")), relerr(m.grad.cpu().numpy(), g.arr(case, "grad64"))
+    ledger_record(f"{case['fn']} value", ev, noise)
+    ledger_record(f"{case['fn']} d/dmat", eg, noise)
+    assert ev < max(TOL, 4 * noise) and eg < max(TOL, 4 * noise), (ev, eg, noise)
+
+
+@pytest.mark.parametrize("Q,n", [(1, 3), (2, 2), (1000, 7), (100_000, 4)])
+def test_risk_functions_vs_oracle(Q, n, dev):
+    from losses.riskLosses.riskFunctions import geoRisk, zRisk
+    gen = torch.Generator().manual_seed(Q + n)
+    m = torch.rand(Q, n, generator=gen) * 0.9 + 0.05
+    for geo, fn in ((False, zRisk), (True, geoRisk)):
+        for i in (0, -1, 1):
+            x = m.to(dev).requires_grad_(True)
+            out = fn(x, 5, requires_grad=True, i=i)
+            out.sum().backward()
+            v, gr = RO.risk_closed_form(m.double(), 5, i, geo)
+            if Q == 1:                # one query: every residual is exactly 0 up to rounding -- compare absolutely
+                assert abs(float(out.detach().sum()) - float(v.sum())) < 1e-5
+                continue
+            assert relerr(out.detach().cpu().numpy(), v.numpy()) < TOL, (geo, i)
+            assert relerr(x.grad.cpu().numpy(), gr.numpy()) < TOL, (geo, i)
+
+
+@pytest.mark.parametrize("S", [8, 32, 128, 200])
+@pytest.mark.parametrize("scheme", ["ndcgLoss2PP_scheme", "lamdbaRank_scheme", "ndcgLoss1_scheme", None])
+def test_pair_colsum_vs_oracle(S, scheme, dev):
+    """Column sums of the pair matrix without the [B,S,S] tensor == sum(dim=1) of the oracle's full matrix; also equal
+    to summing this package's own lambdaMask(return_losses=True); and the backward."""
+    from losses.lambdaL import lambdaMask
+    from ltr_mi355x.risk import lambda_colsum
+    B = 5
+    gen = torch.Generator().manual_seed(S)
+    p = torch.softmax(torch.randn(B, S, generator=gen), dim=1)
+    pt = torch.softmax(torch.randint(0, 5, (B, S), generator=gen).float(), dim=1)
+    x = p.double().clone().requires_grad_(True)
+    ref = RO.pair_colsum(x, pt.double(), scheme)
+    gup = torch.randn(B, S, generator=gen)
+    ref.backward(gup.double())
+    xd = p.to(dev).requires_grad_(True)
+    got = lambda_colsum(xd, pt.to(dev), scheme)
+    got.backward(gup.to(dev))
+    assert relerr(got.detach().cpu().numpy(), ref.detach().numpy()) < TOL
+    assert relerr(xd.grad.cpu().numpy(), x.grad.numpy()) < TOL
+    full = lambdaMask(p.to(dev), pt.to(dev), weighing_scheme=scheme, return_losses=True)
+    assert relerr(got.detach().cpu().numpy(), torch.sum(full, dim=1).cpu().numpy()) < 1e-6
+
+
+@pytest.mark.parametrize("case", [c for c in golden_cases("risk") if c["kind"] == "loss"], ids=lambda c: c["id"])
+def test_risk_losses_golden(case, dev):
+    from losses.riskLosses import riskLosses as RL
+    g = golden("risk")
+    yp, yt = T(g.arr(case, "y_pred"), dev), T(g.arr(case, "y_true"), dev)
+    yb = T(g.arr(case, "y_base"), dev) if g.has(case, "y_base") else None
+    kw = {k: case[k] for k in ("alpha", "listnet_transformation", "return_strategy", "add_ideal_ranking_to_mat", "weighing_scheme")
+          if k in case}
+    x = yp.clone().requires_grad_(True)
+    out = getattr(RL, case["fn"])(x, yt, yb, **kw)
+    assert out.shape == (1,) and out.device.type == "cuda"
+    out.sum().backward()
+    # exact-arithmetic target: the fp64 oracle on the same inputs (pinned to the reference by make_golden_r2.py)
+    xo = T(g.arr(case, "y_pred"), "cpu").double().requires_grad_(True)
+    oo = oracle_risk_loss(case, xo, T(g.arr(case, "y_true"), "cpu").double(),
+                          None if yb is None else T(g.arr(case, "y_base"), "cpu").double())
+    oo.sum().backward()
+    noise = case["ref_fp32_vs_fp64"]
+    ev, eg = relerr(out.detach().cpu().numpy(), oo.detach().numpy()), relerr(x.grad.cpu().numpy(), xo.grad.numpy())
+    ledger_record(f"{case['fn']} value", ev, noise)
+    ledger_record(f"{case['fn']} d/dy_pred", eg, noise)
+    assert ev < max(TOL, 4 * noise) and eg < max(TOL, 4 * noise), (ev, eg, noise)
+    if case.get("pinned", True):
+        # and the reference's own fp32 output, within the reference's own fp32 noise.  Strategies 2 / 3 of the geoRisk
+        # losses subtract two risks of ~0.1-0.6 that the reference rounds to fp32 (its normal cdf is fp32 even for
+        # fp64 inputs, so `noise` above cannot see it): 1 ulp of each is 1e-5 of a difference of 2e-3.
+        bar = max(TOL, 4 * noise, 1e-4 if case["fn"].startswith("geo") and case.get("return_strategy", 1) > 1 else 0.0)
+        assert relerr(out.detach().cpu().numpy(), g.arr(case, "value")) < bar
+        assert relerr(x.grad.cpu().numpy(), g.arr(case, "grad")) < bar
+
+
+def test_risk_loss_errors_and_larger_batch(dev):
+    from losses.riskLosses import riskLosses as RL
+    gen = torch.Generator().manual_seed(5)
+    B, S, nb = 200, 128, 3
+    yp, yt, yb = torch.randn(B, S, generator=gen), torch.randint(0, 5, (B, S), generator=gen).float(), torch.randn(B, S, nb, generator=gen)
+    with pytest.raises(UnboundLocalError):                       # the reference has no transformation 3 for the Lambda losses
+        RL.geoRiskLambdaLoss(yp.to(dev), yt.to(dev), yb.to(dev), listnet_transformation=3)
+    from ltr_mi355x import LtrDeviceError
+    with pytest.raises(LtrDeviceError):
+        RL.geoRiskListnetLoss(yp, yt, yb)
+    assert RL.zRiskListnetLoss(yp.to(dev), yt.to(dev), yb.to(dev), return_strategy=7) is None
+    for fn, ora in ((RL.zRiskLambdaLoss, RO.z_risk_lambda), (RL.geoRiskListnetLoss, RO.geo_risk_listnet)):
+        x = yp.to(dev).requires_grad_(True)
+        out = fn(x, yt.to(dev), yb.to(dev), listnet_transformation=2, return_strategy=1, add_ideal_ranking_to_mat=2)
+        out.sum().backward()
+        xo = yp.double().requires_grad_(True)
+        oo = ora(xo, yt.double(), yb.double(), lt=2, rs=1, add_ideal=2)
+        oo.sum().backward()
+        assert relerr(out.detach().cpu().numpy(), oo.detach().numpy()) < 5e-5
+        assert relerr(x.grad.cpu().numpy(), xo.grad.numpy()) < 5e-5
