@@ -31,7 +31,9 @@ enum {
     LTR_ERR_NULL = -1,   /* required pointer is NULL                      */
     LTR_ERR_SHAPE = -2,  /* B/S/F/n outside what the kernels support       */
     LTR_ERR_PARAM = -3,  /* bad enum / scalar (scheme id, log base, ...)   */
-    LTR_ERR_ALIGN = -4   /* pointer not aligned as the entry point states  */
+    LTR_ERR_ALIGN = -4,  /* pointer not aligned as the entry point states  */
+    LTR_ERR_IO = -5,     /* (host entry points) file cannot be opened/mapped */
+    LTR_ERR_PARSE = -6   /* (host entry points) malformed input line        */
 };
 
 /* Largest slate length the loss kernels take (LDS-resident slate state). */
@@ -109,7 +111,9 @@ int ltr_lambda_colsum_bwd(const float *scores, const float *labels, int B, int S
  *   LTR_RISK_GEO: value[0] = sqrt(mean_q mat[q,col] * Phi(zRisk / Q))
  *   dmat[Q][n_systems] (NULL: forward only) = d value / d mat, analytic (the [d_q < 0] indicator carries none).
  * One workgroup, fp64 accumulation, fixed summation order. */
-enum { LTR_RISK_Z = 0, LTR_RISK_GEO = 1 };
+enum { LTR_RISK_Z = 0, LTR_RISK_GEO = 1,
+       LTR_RISK_ZERO_GUARD = 4 };  /* OR-ed in: e_q == 0 contributes 0 and the (1 + alpha) weight keys on the raw residual --
+                                      the numpy metric's rules, utils/metrics.py:26-36 (getGeoRiskDefault) */
 int ltr_risk_fwd_bwd(const float *mat, int Q, int n_systems, int col, float alpha, int kind, float *value,
                      float *dmat, void *stream);
 
@@ -118,6 +122,19 @@ int ltr_risk_fwd_bwd(const float *mat, int Q, int n_systems, int col, float alph
  *   (unbiased std, torch.std);  dmodel / dbaseline [Q] (may be NULL) = d value / d model, d baseline. */
 int ltr_trisk_fwd_bwd(const float *model, const float *baseline, int Q, float alpha, float *value, float *dmodel,
                       float *dbaseline, void *stream);
+
+/* ---- mNdcg / ndcg / dcg / torchNdcg                                            utils/metrics.py:48-104
+ * Per-query NDCG@k on the device (the reference loops over queries in Python after every epoch,
+ * main_batch_execution.py:173-200).  y_true, y_score: [Q][S] fp32.  k is clamped to S (:54-55).
+ *   gains: LTR_GAINS_LINEAR (y) | LTR_GAINS_EXPONENTIAL (2^y - 1)                                   (:57-62)
+ *   no_relevant != 0: a query whose ideal DCG is 0 scores 1.0, else 0.0                              (:70-71)
+ *   reverse_ties == 0: tied scores rank lower index first (Python's stable sorted(reverse=True), :51 -- the default
+ *   path); != 0: higher index first (np.argsort(...)[::-1] under a stable argsort, :53).
+ * ndcg[Q] and dcg[Q] (either may be NULL) are fp64, like the reference's numpy results; dcg = the un-normalised
+ * DCG@k of :48-65.  torchNdcg(k) (:83-104) = exponential, no_relevant = 0. */
+enum { LTR_GAINS_LINEAR = 0, LTR_GAINS_EXPONENTIAL = 1 };
+int ltr_ndcg_at_k(const float *y_true, const float *y_score, int Q, int S, int k, int gains, int no_relevant,
+                  int reverse_ties, double *ndcg, double *dcg, void *stream);
 
 /* ---- ordinalLoss(y_pred[B,S,n], y_true[B,S], n, padded_value_indicator)  losses/ordinal.py:27-53
  * n_docs = B*S documents, n ordinal probabilities each.  Targets 1[y >= k] are built with the default
@@ -197,6 +214,27 @@ int ltr_fused_step_lambda(int net, const float *X, const float *labels, int B, i
                           uint64_t seed, const uint8_t *keep1, const uint8_t *keep2, int scheme, int k, float sigma,
                           float mu, float eps, float pad, int log_base, float grad_scale, float *slate_loss,
                           float *slate_count, float *partials, int grid, void *stream);
+
+/* =====================================================================================================
+ * Data path in front of the pipeline.
+ *
+ * ---- get_data(info_dataset, type_file)                                        utils/dataset.py:33-69
+ * LETOR / svmlight text ("<label> qid:<q> <fid>:<val> ... # comment") -> packed rows, HOST pointers, N host threads
+ * over an mmap (n_threads <= 0: all cores).  Two calls: scan (documents, feature-id range: sklearn's zero_based="auto"
+ * rule is `min id == 0 ? zero-based : one-based`), then load into caller-allocated arrays in FILE order:
+ *   X[n_docs][n_features] fp32 (absent features 0; values parsed as float64 then cast, like dataset.py:63),
+ *   y[n_docs] fp64 (svmlight labels are float64), qid[n_docs] (-1 if the line has none).
+ * Grouping documents into queries (a new query starts where qid changes, dataset.py:54-60) is the caller's. */
+int ltr_svmlight_scan(const char *path, int64_t *n_docs, int32_t *min_feature_id, int32_t *max_feature_id, int n_threads);
+int ltr_svmlight_load(const char *path, int64_t n_docs, int n_features, int feature_id_base, float *X, double *y,
+                      int64_t *qid, int n_threads);
+
+/* ---- X_train[idx] / y_train[idx] / y_baseline_train[idx]                  main_batch_execution.py:112-117
+ * dst[r][:] = src[idx[r]][:] for r < n_rows (device pointers; rows of row_floats fp32; idx int64, entries outside
+ * [0, src_rows) leave the destination row untouched).  16-byte-per-lane copies when row_floats % 4 == 0 and both
+ * bases are 16-byte aligned.  HBM-bound: every byte is read once and written once. */
+int ltr_gather_rows_f32(const float *src, int64_t src_rows, const int64_t *idx, int64_t n_rows, int64_t row_floats,
+                        float *dst, void *stream);
 
 #ifdef __cplusplus
 }

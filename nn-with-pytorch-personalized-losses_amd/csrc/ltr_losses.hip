@@ -419,6 +419,8 @@ const char *ltr_error_string(int code) {
         case LTR_ERR_SHAPE: return "ltr: shape outside supported range";
         case LTR_ERR_PARAM: return "ltr: invalid parameter";
         case LTR_ERR_ALIGN: return "ltr: pointer not aligned as required";
+        case LTR_ERR_IO: return "ltr: cannot open / map the input file";
+        case LTR_ERR_PARSE: return "ltr: malformed input line";
         default: return code > 0 ? hipGetErrorString((hipError_t)code) : "ltr: unknown error";
     }
 }

@@ -41,8 +41,8 @@ __device__ __forceinline__ double block_sum_f64(double v, double *red) {
 // dmat (optional): d value / d mat[q,j] (closed form; the indicator [d_q < 0] carries no gradient, like the
 // reference's boolean mask).
 __global__ void __launch_bounds__(kRiskThreads)
-risk_kernel(const float *__restrict__ mat, int Q, int n, int col, float alpha, int geo, float *__restrict__ value,
-            float *__restrict__ dmat) {
+risk_kernel(const float *__restrict__ mat, int Q, int n, int col, float alpha, int geo, int guard,
+            float *__restrict__ value, float *__restrict__ dmat) {
     __shared__ double red[kRiskThreads / LTR_WAVE];
     const int tid = threadIdx.x;
     double s_i = 0.0, s_n = 0.0;
@@ -62,10 +62,11 @@ risk_kernel(const float *__restrict__ mat, int Q, int n, int col, float alpha, i
         for (int j = 0; j < n; ++j) t += (double)row[j];
         const double x = (double)row[col];
         const double e = si * (t / nn);
-        const double d = (x - e) / sqrt(e);
-        const double c = d < 0.0 ? 1.0 + (double)alpha : 1.0;
+        const bool dead = guard && e == 0.0;                       // numpy metric: e == 0 contributes 0 (metrics.py:30-33)
+        const double d = dead ? 0.0 : (x - e) / sqrt(e);
+        const double c = (guard ? (x - e < 0.0) : (d < 0.0)) ? 1.0 + (double)alpha : 1.0;
         z_acc += c * d;
-        const double A = c * (-0.5 * (x + e) / (e * sqrt(e)));     // c_q * d d_q / d e_q
+        const double A = dead ? 0.0 : c * (-0.5 * (x + e) / (e * sqrt(e)));     // c_q * d d_q / d e_q
         t1_acc += A * t;
     }
     const double Z = block_sum_f64(z_acc, red);
@@ -88,10 +89,11 @@ risk_kernel(const float *__restrict__ mat, int Q, int n, int col, float alpha, i
         for (int j = 0; j < n; ++j) t += (double)row[j];
         const double x = (double)row[col];
         const double e = si * (t / nn);
-        const double rs = 1.0 / sqrt(e);
+        const bool dead = guard && e == 0.0;
+        const double rs = dead ? 0.0 : 1.0 / sqrt(e);
         const double d = (x - e) * rs;
-        const double c = d < 0.0 ? 1.0 + (double)alpha : 1.0;
-        const double A = c * (-0.5 * (x + e) * rs / e);
+        const double c = (guard ? (x - e < 0.0) : (d < 0.0)) ? 1.0 + (double)alpha : 1.0;
+        const double A = dead ? 0.0 : c * (-0.5 * (x + e) * rs / e);
         const double common = A * si / nn - si * T1 / nn;          // via t_q and via n
         const double own = c * rs + T1;                             // via mat[q,i] itself and via si
         for (int j = 0; j < n; ++j) {
@@ -146,9 +148,11 @@ int ltr_risk_fwd_bwd(const float *mat, int Q, int n_systems, int col, float alph
     if (!mat || !value) return LTR_ERR_NULL;
     if (Q < 1 || n_systems < 1 || n_systems > 4096) return LTR_ERR_SHAPE;
     if (col < 0) col += n_systems;                       /* i = -1: the last system, as Python indexes */
+    const int guard = (kind & LTR_RISK_ZERO_GUARD) ? 1 : 0;
+    kind &= ~LTR_RISK_ZERO_GUARD;
     if (col < 0 || col >= n_systems || (kind != LTR_RISK_Z && kind != LTR_RISK_GEO)) return LTR_ERR_PARAM;
     hipLaunchKernelGGL(risk_kernel, dim3(1), dim3(kRiskThreads), 0, (hipStream_t)stream, mat, Q, n_systems, col, alpha,
-                       kind == LTR_RISK_GEO ? 1 : 0, value, dmat);
+                       kind == LTR_RISK_GEO ? 1 : 0, guard, value, dmat);
     return status();
 }
 

@@ -25,9 +25,10 @@ STUB = {
     "losses/extraExperiment.py": "VALUE = 41\n",
     "losses/riskLosses/riskFunctions.py": "STUB = True\ndef geoRisk(*a, **k): pass\ndef zRisk(*a, **k): pass\n",
     "losses/riskLosses/riskLosses.py": "STUB = True\ndef geoRiskListnetLoss(*a, **k): pass\n",
-    "utils/__init__.py": "",
-    "utils/dataset.py": "def get_data(*a): pass\ndef svmDataset(*a): pass\ndef get_baseline_data(*a): pass\n",
-    "utils/metrics.py": "def mNdcg(*a): pass\n",
+    # `utils` is a NAMESPACE package in the reference (no __init__.py): the overlay must merge with that too
+    "utils/dataset.py": "STUB = True\ndef get_data(*a): pass\ndef svmDataset(*a): pass\ndef get_baseline_data(*a): pass\n",
+    "utils/metrics.py": "STUB = True\ndef mNdcg(*a): pass\n",
+    "utils/computeMetrics.py": "VALUE = 7\n",
 }
 
 # the exact import block of the reference's batch driver (main_batch_execution.py:10-19), then checks
@@ -43,11 +44,11 @@ CHILD = textwrap.dedent("""
     from losses.riskLosses.riskFunctions import geoRisk
     from utils.dataset import get_data, svmDataset, get_baseline_data
     from utils.metrics import mNdcg
-    import losses, architeture, losses.extraExperiment
+    import losses, architeture, losses.extraExperiment, utils.computeMetrics, utils.metrics, utils.dataset
     pkg, stub = sys.argv[1], sys.argv[2]
     inside = lambda m, d: os.path.abspath(sys.modules[m].__file__).startswith(os.path.abspath(d) + os.sep)
     for m in ("losses", "losses.approxNDCG", "losses.lambdaL", "losses.listnet", "architeture",
-              "architeture.doubleLayer", "architeture.tripleLayer"):
+              "architeture.doubleLayer", "architeture.tripleLayer", "utils.metrics", "utils.dataset"):
         assert inside(m, pkg), (m, sys.modules[m].__file__)
     # the risk losses (SURVEY.md row f-1) resolve here once this package provides them, else in the caller's tree
     ours = os.path.exists(os.path.join(pkg, "losses", "riskLosses", "riskLosses.py"))
@@ -55,9 +56,10 @@ CHILD = textwrap.dedent("""
         assert inside(m, pkg if ours else stub), (m, sys.modules[m].__file__)
         assert hasattr(sys.modules[m], "STUB") != ours
     for m in ("architeture.multiLayer", "losses.exactNDCG", "losses.orderScore", "losses.extraExperiment", "config",
-              "utils.metrics"):
+              "utils.computeMetrics"):
         assert inside(m, stub), (m, sys.modules[m].__file__)
-    assert make_model() == "stub-make_model" and losses.extraExperiment.VALUE == 41
+    assert make_model() == "stub-make_model" and losses.extraExperiment.VALUE == 41 and utils.computeMetrics.VALUE == 7
+    assert not hasattr(utils.metrics, "STUB") and not hasattr(utils.dataset, "STUB")
     assert not hasattr(DoubleLayerNet, "STUB") and not hasattr(losses.approxNDCG, "STUB")
     # `from losses import *` binds what the reference's losses/__init__.py binds (:1-5)
     for name in ("approxNDCG", "exactNDCG", "lambdaL", "orderScore", "riskLosses"):
