@@ -26,6 +26,14 @@
 #include <math.h>
 #include <stdlib.h>
 
+// LTR_SPLIT_BF16 = 1 builds the split-precision variant of the slate pipeline behind the SAME C ABI
+// (libltr_mi355x_bf16x3.so): every fp32 GEMM operand is split into three bf16 pieces and multiplied on
+// v_mfma_f32_16x16x32_bf16 with fp32 accumulation (6 of the 9 piece products: error ~2^-24, i.e. fp32-level),
+// see ltr_pipeline_bf16x3.h.  Default (0): exact fp32 on v_mfma_f32_16x16x4_f32.
+#ifndef LTR_SPLIT_BF16
+#define LTR_SPLIT_BF16 0
+#endif
+
 using namespace ltr;
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -47,6 +55,7 @@ __host__ __device__ constexpr bool x_reg_prefetch() { return MODE == 0 /*MODE_FW
 enum { ACT_ID = 0, ACT_RELU_DROP = 1, ACT_SIGMOID = 2 };
 enum { MODE_FWD = 0, MODE_BWD = 1, MODE_FUSED = 2 };
 
+#if !LTR_SPLIT_BF16
 template <int F_, int H1_, int H2_, int A1_, int A2_, int BH1_, int BH2_>
 struct NetT {
     static constexpr int F = F_, H1 = H1_, H2 = H2_, A1 = A1_, A2 = A2_;
@@ -77,6 +86,9 @@ struct NetT {
     static_assert(F % 4 == 0 && H1 % 4 == 0 && H2 % 4 == 0, "feature counts must be multiples of 4");
     static_assert(NT1 % BH1 == 0 && NT2 % BH2 == 0, "band height must divide the dW row-tile count");
 };
+#else
+#include "ltr_pipeline_bf16x3_net.h"
+#endif
 using DoubleNet = NetT<136, 136, 136, ACT_RELU_DROP, ACT_RELU_DROP, 3, 3>;   // doubleLayer.py:54-66
 using TripleNet = NetT<136, 64, 32, ACT_ID, ACT_SIGMOID, 2, 2>;              // tripleLayer.py:5-17
 // the same classes on the reference's 64-feature collection (TD2003, utils/dataset.py:23-30)
@@ -459,6 +471,7 @@ __device__ __forceinline__ void dma_x_rows(const PipeArgs &a, float *Xs, long lo
     }
 }
 
+#if !LTR_SPLIT_BF16
 template <class N, int MODE, int LOSS>
 __global__ void __launch_bounds__(kThreads, 2) slate_pipeline_kernel(const PipeArgs a) {
     constexpr int LD = N::LD;
@@ -796,6 +809,10 @@ __global__ void __launch_bounds__(kThreads, 2) slate_pipeline_kernel(const PipeA
     }
 }
 
+#else
+#include "ltr_pipeline_bf16x3.h"
+#endif
+
 // The keep mask the pipeline's counter-based dropout stream produces (tests / reproducibility tooling).
 __global__ void dropout_mask_kernel(unsigned long long seed, int layer, long long n_docs, int H, uint8_t *out) {
     const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -805,6 +822,7 @@ __global__ void dropout_mask_kernel(unsigned long long seed, int layer, long lon
     out[e] = (keep_word(seed, layer, doc, n >> 5) >> (n & 31)) & 1u;
 }
 
+#if !LTR_SPLIT_BF16
 // Pack nn.Linear parameters into lane-ordered MFMA A-fragments (once per optimizer step; 37k params).
 template <class N>
 __global__ void pack_kernel(const float *__restrict__ W1, const float *__restrict__ b1, const float *__restrict__ W2,
@@ -832,6 +850,8 @@ __global__ void pack_kernel(const float *__restrict__ W1, const float *__restric
     for (int e = gt; e < N::NT2 * 16 + 16; e += stride)
         packed[N::W3_OFF + e] = e < N::H2 ? w3[e] : (e == N::NT2 * 16 ? b3[0] : 0.f);
 }
+
+#endif
 
 // Sum the per-workgroup partials in a fixed order and scatter into the flat gradient
 // [W1 (H1 x F) | b1 (H1) | W2 (H2 x H1) | b2 (H2) | w3 (H2) | b3 (1)]  (= nn.Module parameter order).
@@ -868,11 +888,14 @@ __global__ void reduce_grads_kernel(const float *__restrict__ partials, int npar
     if (e < N::NPARAM && sub == 0) flat[e] = (float)s;
 }
 
+#if !LTR_SPLIT_BF16
 template <class N>
 constexpr size_t pipeline_lds() {
     return sizeof(float) * (size_t)(kTileDocs * N::LD + 2 * kChunkDocs * N::LD + 8 * kTileDocs + N::NT2 * 16 + 16 +
                                     kWaves * N::NT2 * 16 + kThreads + 4 * 32 + 64);
 }
+
+#endif
 
 inline int status() {
     hipError_t e = hipGetLastError();

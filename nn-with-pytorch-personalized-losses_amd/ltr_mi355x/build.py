@@ -1,4 +1,9 @@
-"""Build libltr_mi355x.so in-tree with hipcc for gfx950 (cross-compiles without a GPU)."""
+"""Build libltr_mi355x.so (and its split-precision variant) in-tree with hipcc for gfx950 (cross-compiles without a GPU).
+
+  libltr_mi355x.so         exact fp32 slate pipeline (v_mfma_f32_16x16x4_f32)            -- the default library
+  libltr_mi355x_bf16x3.so  same C ABI, GEMMs as 3-piece bf16 splits on v_mfma_f32_16x16x32_bf16 (-DLTR_SPLIT_BF16=1);
+                           selected with LTR_LIB=<path> (ltr_mi355x._lib) or ltr_mi355x.use_variant("bf16x3")
+"""
 import glob
 import os
 import shutil
@@ -8,32 +13,42 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(os.path.dirname(HERE), "csrc")
 OUT = os.path.join(HERE, "libltr_mi355x.so")
 FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-shared", "-fPIC", "-fno-gpu-rdc"]
+VARIANTS = {"": [], "bf16x3": ["-DLTR_SPLIT_BF16=1"]}
+
+
+def variant_path(variant=""):
+    return OUT if not variant else os.path.join(HERE, f"libltr_mi355x_{variant}.so")
 
 
 def sources():
     return sorted(glob.glob(os.path.join(CSRC, "*.hip")))
 
 
-def is_stale():
-    if not os.path.exists(OUT):
+def is_stale(out=OUT):
+    if not os.path.exists(out):
         return True
-    t = os.path.getmtime(OUT)
+    t = os.path.getmtime(out)
     deps = sources() + glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(
         os.path.join(os.path.dirname(os.path.dirname(HERE)), "include", "*.h"))
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force=False, verbose=True):
+def build(force=False, verbose=True, variant=""):
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
-    if not force and not is_stale():
-        return OUT
-    cmd = [hipcc] + FLAGS + sources() + ["-o", OUT + ".tmp"]
+    out = variant_path(variant)
+    if not force and not is_stale(out):
+        return out
+    cmd = [hipcc] + FLAGS + VARIANTS[variant] + sources() + ["-o", out + ".tmp"]
     if verbose:
         print("[ltr build]", " ".join(cmd), flush=True)
     subprocess.run(cmd, check=True)
-    os.replace(OUT + ".tmp", OUT)
-    return OUT
+    os.replace(out + ".tmp", out)
+    return out
+
+
+def build_all(force=False, verbose=True):
+    return [build(force, verbose, v) for v in VARIANTS]
 
 
 if __name__ == "__main__":
-    build(force=True)
+    build_all(force=True)
