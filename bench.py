@@ -32,6 +32,8 @@ def flops_per_doc(net):
     """Algorithmic FLOPs fwd + bwd (no dX), SURVEY.md section 8(a)/(d)."""
     if net == "double":
         mac = (136 * 136 * 2 + 136) + (136 * 136 * 3 + 136 * 2)      # 92 888
+    elif net == "two64":
+        mac = (136 * 64 + 64) + (136 * 64 + 64)                      # 17 536: fwd + (dW1, dw3); no dX, no dh1
     else:
         mac = (136 * 64 + 64 * 32 + 32) + (136 * 64 + 64 * 32 * 2 + 32 * 2)
     return 2.0 * mac
@@ -75,6 +77,8 @@ def cpu_baseline(net_kind, S, budget_s=12.0):
     if net_kind == "double":
         shapes = {"fc1.weight": (136, 136), "fc1.bias": (136,), "fc2.weight": (136, 136), "fc2.bias": (136,),
                   "fc3.weight": (1, 136), "fc3.bias": (1,)}
+    elif net_kind == "two64":
+        shapes = {"fc1.weight": (64, 136), "fc1.bias": (64,), "fc4.weight": (1, 64), "fc4.bias": (1,)}
     else:
         shapes = {"l1.weight": (64, 136), "l1.bias": (64,), "l2.weight": (32, 64), "l2.bias": (32,),
                   "l3.weight": (1, 32), "l3.bias": (1,)}
@@ -89,6 +93,8 @@ def cpu_baseline(net_kind, S, budget_s=12.0):
             k1 = (torch.rand(B, S, 136) < 0.5).float()
             k2 = (torch.rand(B, S, 136) < 0.5).float()
             s = O.double_layer_forward(x, p, k1, k2)
+        elif net_kind == "two64":
+            s = O.two_layer_forward(x, p)
         else:
             s = O.triple_layer_forward(x, p)
         loss = O.approx_ndcg(s.squeeze(-1), y)
@@ -103,7 +109,7 @@ def cpu_baseline(net_kind, S, budget_s=12.0):
         n += 1
     dt = time.perf_counter() - t0
     return {"value": round(B * n / dt, 1), "unit": "slates/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"{n} steps of B=200 x S={S} x F=136 ({net_kind}LayerNet + approxNDCG + Adam, fp32) in {dt:.1f}s; "
+            "sample": f"{n} steps of B=200 x S={S} x F=136 ({net_kind} net + approxNDCG + Adam, fp32) in {dt:.1f}s; "
                       "oracle restatement of the reference's torch-CPU path (no dX, unlike the reference)"}
 
 
@@ -125,6 +131,35 @@ def self_launch(n):
     sys.exit(rc)
 
 
+def secondary_lines(a):
+    """Second lines measured by CHILD processes with the same shapes (never exec from this GPU-touched process):
+      bf16x3 : the split-precision variant of the pipeline (same C ABI, LTR_LIB) on the headline workload -- reported next to
+               the exact-fp32 headline, not instead of it;
+      two64  : the 136-64-1 two-layer scorer BASELINE.json configs[0] names, the configuration the 60 % HBM target was
+               written for (exact-fp32 library)."""
+    import subprocess
+    here = os.path.abspath(__file__)
+    variant = os.path.join(ROOT, "nn-with-pytorch-personalized-losses_amd", "ltr_mi355x", "libltr_mi355x_bf16x3.so")
+    base = [sys.executable, here, "--steps", str(a.steps), "--warmup", str(a.warmup), "--queries", str(a.queries), "--slate",
+            str(a.slate), "--batch", str(a.batch), "--no-cpu-baseline", "--no-extras"]
+    runs = {"bf16x3": (base + ["--net", "double"], {"LTR_LIB": variant} if os.path.exists(variant) else None),
+            "two64": (base + ["--net", "two64"], {})}
+    out = {}
+    for name, (cmd, env_add) in runs.items():
+        if env_add is None:
+            out[name] = {"error": "variant library not built"}
+            continue
+        try:
+            r = subprocess.run(cmd, env=dict(os.environ, **env_add), capture_output=True, text=True, timeout=600)
+            line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
+            j = json.loads(line)
+            out[name] = {"value": j["value"], "unit": j["unit"], "ms_per_step": j["ms_per_step"], "workload": j["config"]["workload"],
+                         "roofline": {k: j["roofline"][k] for k in ("achieved", "frac", "kernel_ms", "hbm_achieved_GBps", "hbm_frac_of_8TBps")}}
+        except Exception as e:          # a secondary line must never take the headline down
+            out[name] = {"error": f"{type(e).__name__}: {e}"[:200]}
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -133,11 +168,14 @@ def main():
     ap.add_argument("--queries", type=int, default=100_000, help="resident queries per GPU")
     ap.add_argument("--slate", type=int, default=128)
     ap.add_argument("--batch", type=int, default=25_000, help="slates per GPU per step")
-    ap.add_argument("--net", choices=["double", "triple"], default="double")
+    ap.add_argument("--net", choices=["double", "triple", "two64"], default="double",
+                    help="two64 = the 136-64-1 two-layer variant BASELINE.json configs[0] names (bench-only)")
     ap.add_argument("--loss", choices=["approxNDCG", "listnet", "lambdaLoss"], default="approxNDCG",
                     help="headline metric is approxNDCG; lambdaLoss uses ndcgLoss2PP_scheme (main_batch_execution.py:135)")
     ap.add_argument("--eval-mode", action="store_true", help="no dropout (default: training mode, like the reference loop)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="skip the secondary measurements attached to the default headline line (split-precision variant, 136-64-1 net)")
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -166,7 +204,11 @@ def main():
     from ltr_mi355x.scorer import FusedRanker
 
     torch.manual_seed(2020)
-    net = (DoubleLayerNet(F) if a.net == "double" else TripleLayerNet(F)).to(dev)
+    if a.net == "two64":
+        from ltr_mi355x.extra_nets import TwoLayerNet
+        net = TwoLayerNet(F).to(dev)
+    else:
+        net = (DoubleLayerNet(F) if a.net == "double" else TripleLayerNet(F)).to(dev)
     net.train(not a.eval_mode)
     sync_parameters(net)
     Q, S, B = a.queries, a.slate, min(a.batch, a.queries)
@@ -219,7 +261,7 @@ def main():
             "value": round(slates_per_s, 1), "unit": "slates/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(dt / a.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"{a.loss} + {a.net}LayerNet ({'136-136-136-1' if a.net == 'double' else '136-64-32-1'}) "
+            "config": {"workload": f"{a.loss} + {a.net}LayerNet ({dict(double='136-136-136-1', triple='136-64-32-1', two64='136-64-1')[a.net]}) "
                                    f"{'train-mode dropout' if net.training and a.net == 'double' else 'no dropout'}, "
                                    f"{Q} queries x slate {S} x {F} feat fp32 per GPU resident in HBM, "
                                    f"{B} slates per GPU per step, "
@@ -238,6 +280,9 @@ def main():
         }
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(a.net, S)
+        if world == 1 and not a.no_extras and not a.no_cpu_baseline and a.net == "double" and a.loss == "approxNDCG" \
+                and not os.environ.get("LTR_LIB"):
+            out["secondary"] = secondary_lines(a)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

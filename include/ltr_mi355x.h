@@ -161,7 +161,11 @@ int ltr_ordinal_fwd_bwd(const float *y_pred, const float *y_true, int64_t n_docs
  * computes one only because its drivers set requires_grad on the data, main_batch_execution.py:79).
  */
 enum { LTR_NET_DOUBLE = 0, LTR_NET_TRIPLE = 1,         /* 136 input features (MSLR-WEB10K/30K) */
-       LTR_NET_DOUBLE_64 = 2, LTR_NET_TRIPLE_64 = 3 };  /* the same classes on 64 features (TD2003): 64-64-64-1, 64-64-32-1 */
+       LTR_NET_DOUBLE_64 = 2, LTR_NET_TRIPLE_64 = 3,    /* the same classes on 64 features (TD2003): 64-64-64-1, 64-64-32-1 */
+       LTR_NET_TWO_LAYER_64H = 4 };  /* 136 -> 64 -> 1, ReLU: the commented-out two-Linear DoubleLayerNet variant of
+                                        architeture/doubleLayer.py:38-51 (BASELINE.json configs[0]); benchmark use.  No fc2:
+                                        W2 / b2 are NULL in ltr_mlp_pack and the flat gradient is [W1 | b1 | w3 | b3].
+                                        (exact-fp32 library only; the bf16x3 variant rejects it with LTR_ERR_PARAM) */
 enum { LTR_LOSS_APPROXNDCG = 0, LTR_LOSS_LISTNET = 1 };
 
 /* info[0..7] = F, H1, H2, n_params, packed_floats, partial_floats (per workgroup), docs_per_tile, lds_bytes */

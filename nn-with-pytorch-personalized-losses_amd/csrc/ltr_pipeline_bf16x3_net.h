@@ -9,6 +9,7 @@
 template <int F_, int H1_, int H2_, int A1_, int A2_, int BH1_, int BH2_>
 struct NetT {
     static constexpr int F = F_, H1 = H1_, H2 = H2_, A1 = A1_, A2 = A2_;
+    static constexpr bool TWO = false;             // two-layer nets exist in the fp32 library only
     static constexpr int XT = (F + 1 + 15) / 16;    // x feature tiles of 16 incl. the ones feature (dW1 columns)
     static constexpr int XK = (F + 1 + 31) / 32;    // fc1 k-tiles of 32
     static constexpr int NT1 = (H1 + 15) / 16;      // fc1 output tiles

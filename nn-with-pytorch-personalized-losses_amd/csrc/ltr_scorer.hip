@@ -56,9 +56,14 @@ enum { ACT_ID = 0, ACT_RELU_DROP = 1, ACT_SIGMOID = 2 };
 enum { MODE_FWD = 0, MODE_BWD = 1, MODE_FUSED = 2 };
 
 #if !LTR_SPLIT_BF16
-template <int F_, int H1_, int H2_, int A1_, int A2_, int BH1_, int BH2_>
+// TWO_: a two-Linear-layer scorer  w3 . act1(W1 x + b1) + b3  (no fc2: the commented-out 136-64-1 DoubleLayerNet variant of
+// doubleLayer.py:38-51, BASELINE.json configs[0]).  Declared with H2 = H1 and A2 = A1: "h2" is then h1 itself, the
+// backward through fc3 yields dz1 directly, and the fc2 / dh1 / dW2 GEMMs are compiled out.
+template <int F_, int H1_, int H2_, int A1_, int A2_, int BH1_, int BH2_, bool TWO_ = false>
 struct NetT {
     static constexpr int F = F_, H1 = H1_, H2 = H2_, A1 = A1_, A2 = A2_;
+    static constexpr bool TWO = TWO_;
+    static_assert(!TWO_ || (H1_ == H2_ && A1_ == A2_), "two-layer nets are declared with H2 = H1, A2 = A1");
     static constexpr int XT = (F + 1 + 15) / 16;    // x tiles incl. the ones feature at index F
     static constexpr int NT1 = (H1 + 15) / 16;      // fc1 output tiles
     static constexpr int H1T = (H1 + 1 + 15) / 16;  // h1 tiles incl. the ones feature at index H1
@@ -81,7 +86,7 @@ struct NetT {
     static constexpr int P_W3 = P_W2 + NT2 * 16 * H1T * 16;    // [NT2*16]
     static constexpr int P_B3 = P_W3 + NT2 * 16;
     static constexpr int PART = P_B3 + 16;
-    static constexpr int NPARAM = H1 * F + H1 + H2 * H1 + H2 + H2 + 1;
+    static constexpr int NPARAM = TWO ? H1 * F + H1 + H2 + 1 : H1 * F + H1 + H2 * H1 + H2 + H2 + 1;
     static_assert(LD % 32 == 16, "LDS stride must be 16 mod 32 for conflict-free fragment reads");
     static_assert(F % 4 == 0 && H1 % 4 == 0 && H2 % 4 == 0, "feature counts must be multiples of 4");
     static_assert(NT1 % BH1 == 0 && NT2 % BH2 == 0, "band height must divide the dW row-tile count");
@@ -94,15 +99,23 @@ using TripleNet = NetT<136, 64, 32, ACT_ID, ACT_SIGMOID, 2, 2>;              // 
 // the same classes on the reference's 64-feature collection (TD2003, utils/dataset.py:23-30)
 using DoubleNet64 = NetT<64, 64, 64, ACT_RELU_DROP, ACT_RELU_DROP, 2, 2>;
 using TripleNet64 = NetT<64, 64, 32, ACT_ID, ACT_SIGMOID, 2, 2>;
+#if !LTR_SPLIT_BF16
+using TwoLayerNet64h = NetT<136, 64, 64, ACT_RELU_DROP, ACT_RELU_DROP, 2, 2, true>;   // 136 -> 64 -> 1 (bench-only)
+#define LTR_FOR_NET_EXTRA(...) case LTR_NET_TWO_LAYER_64H: { using NET = TwoLayerNet64h; __VA_ARGS__; } break;
+#else
+#define LTR_FOR_NET_EXTRA(...)           /* the split-precision variant compiles the reference's live classes only */
+#endif
 
-// run `expr` with NET bound to the network type of id `net` (LTR_NET_*); unknown ids -> LTR_ERR_PARAM
-#define LTR_FOR_NET(net, expr)                                             \
-    switch (net) {                                                         \
-        case LTR_NET_DOUBLE: { using NET = DoubleNet; expr; } break;       \
-        case LTR_NET_TRIPLE: { using NET = TripleNet; expr; } break;       \
-        case LTR_NET_DOUBLE_64: { using NET = DoubleNet64; expr; } break;  \
-        case LTR_NET_TRIPLE_64: { using NET = TripleNet64; expr; } break;  \
-        default: return LTR_ERR_PARAM;                                     \
+// run the statement(s) given after `net` with NET bound to the network type of id `net` (LTR_NET_*); unknown ids ->
+// LTR_ERR_PARAM.  Variadic: the statement may contain top-level commas (kernel launches).
+#define LTR_FOR_NET(net, ...)                                                     \
+    switch (net) {                                                                \
+        case LTR_NET_DOUBLE: { using NET = DoubleNet; __VA_ARGS__; } break;       \
+        case LTR_NET_TRIPLE: { using NET = TripleNet; __VA_ARGS__; } break;       \
+        case LTR_NET_DOUBLE_64: { using NET = DoubleNet64; __VA_ARGS__; } break;  \
+        case LTR_NET_TRIPLE_64: { using NET = TripleNet64; __VA_ARGS__; } break;  \
+        LTR_FOR_NET_EXTRA(__VA_ARGS__)                                            \
+        default: return LTR_ERR_PARAM;                                            \
     }
 
 struct PipeArgs {
@@ -596,11 +609,16 @@ __global__ void __launch_bounds__(kThreads, 2) slate_pipeline_kernel(const PipeA
         LTR_STAMP(2)
         // ---- fc2
         f32x4 h2[N::NT2];
-        if (!LTR_SKIP(a, 8)) gemm_wx<N::NT2, N::H1T>(wrsrc, N::W2F_OFF * 4, lane_off, h1, h2);
-        else
+        if (N::TWO) {       // no fc2: the last hidden layer IS h1
 #pragma unroll
             for (int To = 0; To < N::NT2; ++To) h2[To] = h1[To];
-        activate<N::A2, N::H2, N::NT2>(h2, q, a, 1, a.keep2, gdoc);
+        } else {
+            if (!LTR_SKIP(a, 8)) gemm_wx<N::NT2, N::H1T>(wrsrc, N::W2F_OFF * 4, lane_off, h1, h2);
+            else
+#pragma unroll
+                for (int To = 0; To < N::NT2; ++To) h2[To] = h1[To];
+            activate<N::A2, N::H2, N::NT2>(h2, q, a, 1, a.keep2, gdoc);
+        }
         LTR_STAMP(3)
         // ---- fc3: s = w3 . h2 + b3, reduced over the 4 q-lanes of each document
         {
@@ -713,7 +731,7 @@ __global__ void __launch_bounds__(kThreads, 2) slate_pipeline_kernel(const PipeA
         LTR_STAMP(6)
         // ---- dW2 += dz2^T [h1 | 1] over the two 64-document chunks (tiles of waves 0-3, then waves 4-7)
 #pragma unroll
-        for (int c = 0; c < 2; ++c) {
+        for (int c = 0; c < (N::TWO ? 0 : 2); ++c) {
             if (c > 0) __syncthreads();   // chunk 0 fully consumed
             if (chunk == c) {
 #pragma unroll
@@ -731,12 +749,15 @@ __global__ void __launch_bounds__(kThreads, 2) slate_pipeline_kernel(const PipeA
         // ---- dh1^T = W2^T dz2^T  (A = packed W2^T fragments, B = dz2 registers), then
         //      dz1 = dh1 * act1'(h1), features >= H1 (incl. the ones feature) zeroed
         f32x4 dz1[N::NT1];
-        if (!LTR_SKIP(a, 4)) gemm_wx<N::NT1, N::NT2>(wrsrc, N::W2T_OFF * 4, lane_off, h2, dz1);
+        if (N::TWO) {       // the backward through fc3 above already produced dz1 (A2 = A1, "h2" = h1)
+#pragma unroll
+            for (int To = 0; To < N::NT1; ++To) dz1[To] = h2[To];
+        } else if (!LTR_SKIP(a, 4)) gemm_wx<N::NT1, N::NT2>(wrsrc, N::W2T_OFF * 4, lane_off, h2, dz1);
         else
 #pragma unroll
             for (int To = 0; To < N::NT1; ++To) dz1[To] = h2[To < N::NT2 ? To : 0];
 #pragma unroll
-        for (int To = 0; To < N::NT1; ++To)
+        for (int To = 0; To < (N::TWO ? 0 : N::NT1); ++To)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const float gsc = (N::A1 == ACT_RELU_DROP) ? dz1[To][r] * slope : dz1[To][r];
@@ -792,7 +813,7 @@ __global__ void __launch_bounds__(kThreads, 2) slate_pipeline_kernel(const PipeA
     // ---- per-workgroup partial gradients -> workspace
     float *part = a.partials + (size_t)blockIdx.x * N::PART;
     dw_store<N::TW1, N::NT1, N::XT, N::BH1>(w, accW1, part + N::P_W1, q, d);
-    dw_store<N::TW2, N::NT2, N::H1T, N::BH2>(w, accW2, part + N::P_W2, q, d);
+    if (!N::TWO) dw_store<N::TW2, N::NT2, N::H1T, N::BH2>(w, accW2, part + N::P_W2, q, d);
     __syncthreads();
     for (int j = tid; j < N::NT2 * 16; j += kThreads) {
         float s = 0.f;
@@ -837,12 +858,12 @@ __global__ void pack_kernel(const float *__restrict__ W1, const float *__restric
         const int s = e & 3, lane = (e >> 2) & 63, tile = e >> 8, To = tile / N::XT, T = tile - To * N::XT;
         packed[N::W1F_OFF + e] = w1aug(16 * To + (lane & 15), 16 * T + 4 * (lane >> 4) + s);
     }
-    for (int e = gt; e < N::NT2 * N::H1T * 256; e += stride) {
+    for (int e = gt; e < (N::TWO ? 0 : N::NT2 * N::H1T * 256); e += stride) {
         const int s = e & 3, lane = (e >> 2) & 63, tile = e >> 8, To = tile / N::H1T, T = tile - To * N::H1T;
         packed[N::W2F_OFF + e] = w2aug(16 * To + (lane & 15), 16 * T + 4 * (lane >> 4) + s);
     }
     // W2^T fragments for dh1: output tile Ti over fc2 INPUT features, k over fc2 OUTPUT features
-    for (int e = gt; e < N::NT1 * N::NT2 * 256; e += stride) {
+    for (int e = gt; e < (N::TWO ? 0 : N::NT1 * N::NT2 * 256); e += stride) {
         const int s = e & 3, lane = (e >> 2) & 63, tile = e >> 8, Ti = tile / N::NT2, T = tile - Ti * N::NT2;
         const int in = 16 * Ti + (lane & 15), o = 16 * T + 4 * (lane >> 4) + s;
         packed[N::W2T_OFF + e] = (o < N::H2 && in < N::H1) ? W2[o * N::H1 + in] : 0.f;
@@ -871,11 +892,11 @@ __global__ void reduce_grads_kernel(const float *__restrict__ partials, int npar
             off = N::P_W1 + (k / N::F) * (N::XT * 16) + (k % N::F);
         } else if ((k -= N::H1 * N::F) < N::H1) {
             off = N::P_W1 + k * (N::XT * 16) + N::F;
-        } else if ((k -= N::H1) < N::H2 * N::H1) {
+        } else if (!N::TWO && (k -= N::H1) < N::H2 * N::H1) {
             off = N::P_W2 + (k / N::H1) * (N::H1T * 16) + (k % N::H1);
-        } else if ((k -= N::H2 * N::H1) < N::H2) {
+        } else if (!N::TWO && (k -= N::H2 * N::H1) < N::H2) {
             off = N::P_W2 + k * (N::H1T * 16) + N::H1;
-        } else if ((k -= N::H2) < N::H2) {
+        } else if ((k -= (N::TWO ? N::H1 : N::H2)) < N::H2) {
             off = N::P_W3 + k;
         } else {
             off = N::P_B3;
@@ -959,7 +980,8 @@ int ltr_dropout_keep_mask(uint64_t seed, int layer, int64_t n_docs, int H, uint8
 
 int ltr_mlp_pack(int net, const float *W1, const float *b1, const float *W2, const float *b2, const float *w3,
                  const float *b3, float *packed, void *stream) {
-    if (!W1 || !b1 || !W2 || !b2 || !w3 || !b3 || !packed) return LTR_ERR_NULL;
+    if (!W1 || !b1 || !w3 || !b3 || !packed) return LTR_ERR_NULL;
+    if ((!W2 || !b2) && net != LTR_NET_TWO_LAYER_64H) return LTR_ERR_NULL;     /* two-layer nets have no fc2 */
     if (!aligned16(packed)) return LTR_ERR_ALIGN;
     LTR_FOR_NET(net, hipLaunchKernelGGL(pack_kernel<NET>, dim3(64), dim3(256), 0, (hipStream_t)stream, W1, b1, W2, b2, w3,
                                         b3, packed))
@@ -982,7 +1004,7 @@ int ltr_debug_set_stamps(void *buf, int tile) {
 static int fill_common(PipeArgs &a, int net, const float *X, int64_t n_docs, const float *packed, int dropout,
                        uint64_t seed, const uint8_t *keep1, const uint8_t *keep2) {
     if (!X || !packed) return LTR_ERR_NULL;
-    if (net < LTR_NET_DOUBLE || net > LTR_NET_TRIPLE_64) return LTR_ERR_PARAM;
+    if (net < LTR_NET_DOUBLE || net > LTR_NET_TWO_LAYER_64H) return LTR_ERR_PARAM;
     if (n_docs < 0 || n_docs > ((int64_t)1 << 37)) return LTR_ERR_SHAPE;
     if (!aligned16(X) || !aligned16(packed)) return LTR_ERR_ALIGN;
     a = PipeArgs{};

@@ -15,7 +15,7 @@ import torch
 from ._lib import LtrError, check, lib
 from .functional import _ptr, _stream, require_device
 
-NET_DOUBLE, NET_TRIPLE, NET_DOUBLE_64, NET_TRIPLE_64 = 0, 1, 2, 3
+NET_DOUBLE, NET_TRIPLE, NET_DOUBLE_64, NET_TRIPLE_64, NET_TWO_LAYER_64H = 0, 1, 2, 3, 4
 COMPILED_FEATURES = {136: (NET_DOUBLE, NET_TRIPLE), 64: (NET_DOUBLE_64, NET_TRIPLE_64)}
 
 
@@ -39,7 +39,10 @@ class NetInfo:
         (self.F, self.H1, self.H2, self.n_params, self.packed_floats, self.partial_floats, self.tile_docs,
          self.lds_bytes) = list(buf)
         self.net = net
-        self.shapes = [(self.H1, self.F), (self.H1,), (self.H2, self.H1), (self.H2,), (1, self.H2), (1,)]
+        # two-Linear-layer nets (no fc2) carry [W1, b1, w3, b3] only
+        self.two_layer = self.n_params == self.H1 * self.F + self.H1 + self.H2 + 1
+        self.shapes = ([(self.H1, self.F), (self.H1,), (1, self.H2), (1,)] if self.two_layer else
+                       [(self.H1, self.F), (self.H1,), (self.H2, self.H1), (self.H2,), (1, self.H2), (1,)])
 
     @classmethod
     def get(cls, net):
@@ -76,13 +79,18 @@ def pack_params(net, params, out=None):
     """nn.Linear weights/biases [W1,b1,W2,b2,w3,b3] -> lane-ordered MFMA fragments (ltr_mlp_pack)."""
     info = NetInfo.get(net)
     ps = _params_f32(params)
+    if len(ps) != len(info.shapes):
+        raise ValueError(f"expected {len(info.shapes)} parameter tensors, got {len(ps)}")
     for t, shape in zip(ps, info.shapes):
         if tuple(t.shape) != shape:
             raise ValueError(f"parameter shape {tuple(t.shape)} != expected {shape}")
     dev = ps[0].device
     if out is None:
         out = torch.empty(info.packed_floats, dtype=torch.float32, device=dev)
-    check(lib().ltr_mlp_pack(net, *[_ptr(t) for t in ps], _ptr(out), _stream()), "ltr_mlp_pack")
+    ptrs = [_ptr(t) for t in ps]
+    if info.two_layer:
+        ptrs = ptrs[:2] + [None, None] + ptrs[2:]          # no fc2: W2 / b2 are NULL in the C ABI
+    check(lib().ltr_mlp_pack(net, *ptrs, _ptr(out), _stream()), "ltr_mlp_pack")
     return out
 
 

@@ -349,3 +349,11 @@ def triple_layer_forward(x, p):
     h = x @ p["l1.weight"].T + p["l1.bias"]
     h = torch.sigmoid(h @ p["l2.weight"].T + p["l2.bias"])
     return h @ p["l3.weight"].T + p["l3.bias"]
+
+
+def two_layer_forward(x, p):
+    """The two-Linear-layer DoubleLayerNet variant the reference keeps commented out (architeture/doubleLayer.py:38-51):
+    fc4(relu(fc1 x)), 136 -> 64 -> 1 (BASELINE.json configs[0]).  Its log_softmax(dim=1) only shifts each slate's scores
+    by a constant (irrelevant to every listwise loss here) and is omitted, as in the device module."""
+    h = torch.relu(x @ p["fc1.weight"].T + p["fc1.bias"])
+    return h @ p["fc4.weight"].T + p["fc4.bias"]

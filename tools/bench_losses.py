@@ -32,9 +32,13 @@ def main():
     dev = torch.device("cuda:0")
     h = lib()
     out = []
-    for name, B, S in (("approxndcg", 100_000, 32), ("approxndcg", 100_000, 128), ("approxndcg", 16_384, 512),
-                       ("lambda2pp", 100_000, 32), ("lambda2pp", 100_000, 128), ("lambda2pp", 8_192, 512),
-                       ("listnet", 100_000, 32), ("listnet", 100_000, 128), ("listnet", 16_384, 512)):
+    cases = (("approxndcg", 100_000, 32), ("approxndcg", 100_000, 128), ("approxndcg", 16_384, 512),
+             ("lambda2pp", 100_000, 32), ("lambda2pp", 100_000, 128), ("lambda2pp", 8_192, 512),
+             ("listnet", 100_000, 32), ("listnet", 100_000, 128), ("listnet", 16_384, 512))
+    if "--only" in sys.argv:           # e.g. --only lambda512 (BASELINE config 3 shape, for profiling one kernel)
+        want = sys.argv[sys.argv.index("--only") + 1]
+        cases = tuple(c for c in cases if f"{c[0].replace('2pp', '')}{c[2]}" == want)
+    for name, B, S in cases:
         s = torch.randn(B, S, device=dev)
         y = torch.randint(0, 5, (B, S), device=dev).float()
         sl = torch.empty(B, device=dev)
