@@ -1,8 +1,8 @@
 """Build libltr_mi355x.so (and its split-precision variant) in-tree with hipcc for gfx950 (cross-compiles without a GPU).
 
   libltr_mi355x.so         exact fp32 slate pipeline (v_mfma_f32_16x16x4_f32)            -- the default library
-  libltr_mi355x_bf16x3.so  same C ABI, GEMMs as 3-piece bf16 splits on v_mfma_f32_16x16x32_bf16 (-DLTR_SPLIT_BF16=1);
-                           selected with LTR_LIB=<path> (ltr_mi355x._lib) or ltr_mi355x.use_variant("bf16x3")
+  libltr_mi355x_bf16x3.so  same C ABI, ALL GEMMs as 3-piece bf16 splits on v_mfma_f32_16x16x32_bf16 (-DLTR_SPLIT_BF16=1);
+                           selected with LTR_LIB=<path> (ltr_mi355x._lib)
 """
 import glob
 import os
