@@ -141,6 +141,41 @@ lambda_kernel(const float *__restrict__ scores, const float *__restrict__ labels
     }
 }
 
+// Long slates (256 <= S <= 1024, every scheme but ndcgLoss1): rank-space sweep, every unordered pair once
+// (lambda_slate_blocked).  One slate per workgroup, one wave per 64 ranks.
+template <int SCH>
+__global__ void __launch_bounds__(1024)
+lambda_blocked_kernel(const float *__restrict__ scores, const float *__restrict__ labels, int B, int S, LambdaParams P,
+                      float pad, float gscale, float *__restrict__ slate_loss, float *__restrict__ slate_count,
+                      float *__restrict__ dscores) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int s_al = (S + 3) & ~3, s64 = (S + 63) & ~63;
+    const int slate = blockIdx.x;
+    const LambdaLds L = lambda_carve(smem, s_al);
+    float *rb = smem + kLambdaArrays * s_al;
+    LambdaRankLds R;
+    R.rs = rb;
+    R.ry = rb + s64;
+    R.rg = rb + 2 * s64;
+    R.colacc = rb + 3 * s64;
+    R.doc_of = reinterpret_cast<int *>(rb + 4 * s64);
+    const SlateGroup g = make_group(S, blockDim.x, rb + 5 * s64);
+    const size_t off = (size_t)slate * S;
+    for (int j = g.t; j < S; j += blockDim.x) {
+        L.sc[j] = scores[off + j];
+        stage_label(labels[off + j], pad, L.yl[j], L.gn[j]);
+    }
+    __syncthreads();
+    float *dst = dscores ? dscores + off : nullptr;
+    float count;
+    const float loss = lambda_slate_blocked<SCH>(g, L, R, P, gscale, dscores != nullptr, &count,
+                                                 [&](int i, float v) { dst[i] = v; });
+    if (g.t == 0) {
+        slate_loss[slate] = loss;
+        slate_count[slate] = count;
+    }
+}
+
 // Full pair matrix in predicted-rank order (lambdaMask(return_losses=True), lambdaL.py:49-60): every
 // (ri, rj) including padded documents, whose score/label are -inf in the reference (:13-15):
 //   d = clamp(s_i - s_j, +-1e8), NaN -> 0;  G = 0 and clamped label = 0 for padded documents.
@@ -467,6 +502,25 @@ int ltr_lambda_fwd_bwd(const float *scores, const float *labels, int B, int S, i
     LambdaParams P;
     if (int rc = make_lambda_params(scheme, k, sigma, mu, eps, log_base, &P)) return rc;
     if (B == 0) return LTR_OK;
+    if (S >= 256 && S <= 1024 && scheme != LTR_SCHEME_NDCG_LOSS1) {
+        const int s_al = (S + 3) & ~3, s64 = (S + 63) & ~63;
+        const size_t lds = (size_t)(kLambdaArrays * s_al + 5 * s64 + s64 + 32) * sizeof(float);
+#define CALLB(SCH)                                                                                                \
+    if (int rc = allow_lds(lambda_blocked_kernel<SCH>, lds)) return rc;                                           \
+    hipLaunchKernelGGL(lambda_blocked_kernel<SCH>, dim3(B), dim3(s64), lds, (hipStream_t)stream, scores, labels,  \
+                       B, S, P, pad, grad_scale, slate_loss, slate_count, dscores)
+        switch (scheme) {
+            case 0: { CALLB(0); break; }
+            case 2: { CALLB(2); break; }
+            case 3: { CALLB(3); break; }
+            case 4: { CALLB(4); break; }
+            case 5: { CALLB(5); break; }
+            case 6: { CALLB(6); break; }
+            default: { CALLB(7); break; }
+        }
+#undef CALLB
+        return launch_status();
+    }
     const SlateLaunch L = plan(B, S, kLambdaArrays);
 #define CALL(SCH)                                                                                                 \
     if (int rc = allow_lds(lambda_kernel<SCH>, L.lds)) return rc;                                                 \

@@ -485,4 +485,103 @@ __device__ __forceinline__ float lambda_slate(const SlateGroup &g, const LambdaL
     return -total;
 }
 
+// ------------------------------------------------------------------------------------------------
+// LambdaLoss for long slates (S >= 256), RANK SPACE + every unordered pair ONCE.
+//
+// The slate is first permuted into predicted-rank order (the order the reference sorts into, lambdaL.py:17-21): row r
+// of the pair matrix is then "the document ranked r", so the rank-dependent inputs of the weighing schemes stop being
+// data -- 1/D_r is a table indexed by the lane's own row, delta_{|ri - rj|} is delta[|r - c|] with CONSECUTIVE lanes
+// reading CONSECUTIVE entries (conflict-free, against a random per-lane gather and 55 % LDS bank-conflict cycles in
+// the document-order sweep), the top-k mask is r < k && c < k.  Every scheme but ndcgLoss1 keeps a pair in exactly one
+// orientation with a symmetric weight, and the gradient of a pair is antisymmetric (+g on one document, -g on the
+// other): the S x S matrix is cut into 64 x 64 blocks, wave v owns block-row v, and in round t it evaluates block
+// (v, v + t mod nb) -- each unordered block pair once (t = 0: the upper triangle of the diagonal block; t = nb/2 for
+// even nb: only v < nb/2).  Row sums stay in the lane's registers; the column side of block (v, u) is reduced across
+// the wave per column (DPP butterfly, ~10 VALU per 64 pairs) and added to colacc[] of block u -- in one round every
+// wave writes a different column block and rounds are separated by a barrier, so the result is bit-reproducible.
+// 40 VALU per unordered pair against 2 x 41 in the document-order sweep.
+//
+// Group layout: one wave per 64 ranks (blockDim = 64 * nb, nb = ceil(S / 64) <= 16).  LDS (floats, s64 = 64 nb each):
+//   L.* as for lambda_prepare, plus rs / ry / rg (score, clamped label -- -1 for padded --, G by rank), colacc, doc_of.
+struct LambdaRankLds {
+    float *rs, *ry, *rg, *colacc;
+    int *doc_of;
+};
+
+template <int SCH, class Store>
+__device__ __forceinline__ float lambda_slate_blocked(const SlateGroup &g, const LambdaLds &L, const LambdaRankLds &R,
+                                                      const LambdaParams &P, float gscale, bool want_grad,
+                                                      float *count_out, Store store) {
+    static_assert(SCH != 1, "ndcgLoss1 keeps both orientations of every pair: served by lambda_slate");
+    lambda_prepare(g, L, P);                       // ranks by counting, G, delta table (ends with a barrier)
+    const int S = g.S;
+    const int nb = (S + 63) >> 6, s64 = nb << 6;
+    const int lane = threadIdx.x & 63, v = g.t >> 6;          // wave v of the group owns ranks 64 v .. 64 v + 63
+    // ---- permute into rank order (padded documents rank last; ranks >= S are filler)
+    float *invr = L.w1;                            // 1 / D_r by RANK (w1 itself is only used by ndcgLoss1)
+    for (int r = g.t; r < s64; r += g.group) {
+        R.rg[r] = -1.f;
+        R.rs[r] = 0.f;
+        R.ry[r] = 0.f;
+        R.colacc[r] = 0.f;
+        R.doc_of[r] = -1;
+        if (r < ((S + 3) & ~3)) invr[r] = 1.f / log2f(2.f + (float)r);
+    }
+    __syncthreads();
+    for (int i = g.t; i < S; i += g.group) {
+        const int r = L.rk[i];
+        R.rs[r] = L.sc[i];
+        R.rg[r] = L.gn[i];                                     // G, -1 for padded documents
+        R.ry[r] = L.yl[i];                                     // raw label (-inf if padded): pairs compare raw labels (:24-27)
+        R.doc_of[r] = i;
+    }
+    __syncthreads();
+    const int row = 64 * v + lane;                             // this lane's rank
+    const float si = R.rs[row], Gi = R.rg[row], yi = R.ry[row];
+    const bool vi = Gi >= 0.f && (P.k <= 0 || row < P.k);
+    const float invi = row < S ? invr[row] : 0.f;
+    float ls = 0.f, cn = 0.f, gr = 0.f;
+    for (int t = 0; 2 * t <= nb; ++t) {
+        const int u = v + t < nb ? v + t : v + t - nb;         // column block of this round
+        const bool active = (2 * t < nb) || (v < nb / 2);      // t == nb/2 (even nb): each block pair only once
+        float colreg = 0.f;                                    // lane c holds the column-side sum of column 64 u + c
+        if (active) {
+            for (int c0 = 0; c0 < 64; ++c0) {
+                const int col = 64 * u + c0;
+                const float sj = R.rs[col], Gj = R.rg[col], yj = R.ry[col];      // broadcast reads
+                const bool vj = Gj >= 0.f && (P.k <= 0 || col < P.k);
+                const bool pair = vi && vj && yi != yj && (t > 0 || c0 > lane);   // diagonal block: upper triangle only
+                const float draw = si - sj;
+                const float dcl = fminf(fmaxf(draw, -1e8f), 1e8f);
+                const bool dlive = fabsf(draw) <= 1e8f;
+                float uu, um;
+                sigmoid_pair(P.sigma * dcl, uu, um);
+                const bool hi = yi > yj;                                          // this lane's document is the first of the kept pair
+                const float invj = col < S ? invr[col] : 0.f;                     // broadcast read
+                const float w = lambda_weight<SCH>(P, L.delta, row, col, invi, invj, 0.f, fmaxf(Gi, 0.f), fmaxf(Gj, 0.f),
+                                                   fmaxf(yi, 0.f), fmaxf(yj, 0.f));
+                float ell, dl;
+                lambda_pair_term(P, w, hi ? uu : um, hi ? um : uu, ell, dl);
+                ls += pair ? ell : 0.f;
+                cn += pair ? 1.f : 0.f;
+                const float gi = (pair && dlive) ? (hi ? -dl : dl) : 0.f;         // d loss-sum / d s_row; the column document gets -gi
+                gr += gi;
+                if (want_grad) {
+                    const float csum = wave_allsum(-gi);
+                    colreg = lane == c0 ? csum : colreg;
+                }
+            }
+            if (want_grad) R.colacc[64 * u + lane] += colreg;  // this round, this wave is the only writer of block u
+        }
+        __syncthreads();                                       // next round writes a different column block per wave
+    }
+    const float total = group_sum(g, ls);
+    *count_out = group_sum(g, cn);
+    if (want_grad && row < s64) {
+        const int doc = R.doc_of[row];
+        if (doc >= 0) store(doc, gscale * P.sigma * (gr + R.colacc[row]));
+    }
+    return -total;
+}
+
 }  // namespace ltr
