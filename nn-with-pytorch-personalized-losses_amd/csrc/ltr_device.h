@@ -133,15 +133,18 @@ inline int pick_group(int S) {
     return g;
 }
 
-__device__ __forceinline__ SlateGroup make_group(int S, int group, float *scratch /* [group + 32] */) {
+// `tid`: the thread's index in the block.  Persistent kernels pass a value laundered through an empty asm inside their
+// tile loop so that the group geometry is recomputed per tile (a dozen integer ops) instead of being hoisted out of the
+// loop and kept alive -- in a kernel at its register limit those hoisted values end up in scratch.
+__device__ __forceinline__ SlateGroup make_group(int S, int group, float *scratch /* [group + 32] */, int tid) {
     SlateGroup g;
     g.S = S;
     g.group = group;
     int np2 = next_pow2(S);
     g.sp = np2 < group ? np2 : group;
     g.CG = group / g.sp;
-    int gid = threadIdx.x / group;
-    g.t = threadIdx.x - gid * group;
+    int gid = tid / group;
+    g.t = tid - gid * group;
     g.ri = g.t / g.CG;          // row lane; its CG column groups are adjacent lanes (see row_reduce)
     g.cg = g.t & (g.CG - 1);
     g.wig = g.t / LTR_WAVE;
@@ -149,6 +152,10 @@ __device__ __forceinline__ SlateGroup make_group(int S, int group, float *scratc
     g.part = scratch;
     g.red = scratch + group;
     return g;
+}
+
+__device__ __forceinline__ SlateGroup make_group(int S, int group, float *scratch) {
+    return make_group(S, group, scratch, (int)threadIdx.x);
 }
 
 // sigmoid pair of x: big = sigma(|x|), small = sigma(-|x|), without overflow and with full relative

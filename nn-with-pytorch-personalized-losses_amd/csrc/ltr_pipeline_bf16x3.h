@@ -246,8 +246,16 @@ __global__ void __launch_bounds__(kThreads, 2) slate_pipeline_kernel(const PipeA
     }
     const int my_row = 16 * w + d;                         // this lane's document inside the super-tile
 
+    const int lane_outer = lane;
     for (int st = blockIdx.x; st < a.n_super; st += gridDim.x) {
         const long long doc_base = (long long)st * kTileDocs;
+        // per-lane geometry re-derived per tile from a laundered lane id (see the fp32 kernel: keeps hipcc from hoisting
+        // dozens of LDS addresses out of the persistent loop and spilling them)
+        int lane = lane_outer;
+        asm volatile("" : "+v"(lane));
+        const int q = lane >> 4, d = lane & 15;
+        const int my_row = 16 * w + d;
+        const int tid = 64 * w + lane;
         const long long gdoc = doc_base + my_row;
         LTR_STAMP(0)
         __syncthreads();   // previous super-tile done with the images, the staging region and sc / dsc
@@ -323,7 +331,7 @@ __global__ void __launch_bounds__(kThreads, 2) slate_pipeline_kernel(const PipeA
             __syncthreads();
             const int group = 4 * a.S;                 // S in {32, 64, 128}: 4 threads per document row
             const int gid = tid / group;
-            const SlateGroup g = make_group(a.S, group, scratch + gid * (group + 32));
+            const SlateGroup g = make_group(a.S, group, scratch + gid * (group + 32), tid);
             const int so = gid * a.S;
             const long long slate = (long long)st * (kTileDocs / a.S) + gid;
             float loss;

@@ -44,7 +44,10 @@ constexpr int kTileDocs = 128;   // documents per super-tile
 constexpr int kWaves = 8;        // 2 waves per SIMD: the co-resident wave hides LDS / L2 latency
 constexpr int kThreads = kWaves * 64;
 constexpr int kChunkDocs = 64;   // documents per dW staging chunk (the 16-doc tiles of 4 waves)
-constexpr int kRing = 6;         // weight fragments kept in flight per wave (1 KiB each, L2 -> registers)
+#ifndef LTR_RING
+#define LTR_RING 6
+#endif
+constexpr int kRing = LTR_RING;  // weight fragments kept in flight per wave (1 KiB each, L2 -> registers)
 // Next-X-tile prefetch policy, per kernel instantiation (A/B on MI355X, profiles/r01_variant_ab.json):
 //   registers (36 VGPRs live across the loop) where they are free: forward-only kernels -8..-19 %, the 136-64-32
 //   net's fused kernel -4 %;  L2-only prefetch (one dword per 128-B line) for the 136-136-136 backward/fused
@@ -553,8 +556,21 @@ __global__ void __launch_bounds__(kThreads, 2) slate_pipeline_kernel(const PipeA
             *reinterpret_cast<f32x4 *>(Xs + r * LD + N::F + 4 * c4) = v;
         }
     }
+    const int lane_outer = lane;
     for (int st = blockIdx.x; st < a.n_super; st += gridDim.x) {
         const long long doc_base = (long long)st * kTileDocs;
+        // Per-lane geometry is re-derived per tile from a laundered lane id: left loop-invariant, hipcc hoists the dozens
+        // of LDS addresses built from it out of the persistent loop and, at the register limit, parks them in scratch.
+        // (Only where registers are the limit -- the 136-wide backward / fused kernels, 6.78 -> 6.48 ms; the 136-64-32
+        // net and the forward-only kernels have registers to spare and lose 3-4 % to the recomputation.)
+        constexpr bool DEHOIST = N::H1 > 64 && MODE != MODE_FWD;
+        int lane = lane_outer;
+        if (DEHOIST) asm volatile("" : "+v"(lane));
+        const int q = lane >> 4, d = lane & 15;
+        const int my_row = 16 * w + d;
+        const int crow = 16 * (w & 3) + d;
+        const int lane_off = lane * 16;
+        const int tid = 64 * w + lane;
         LTR_STAMP(0)
         __syncthreads();   // previous super-tile done with Xs / sc / dsc
         // ---- X: HBM -> LDS, coalesced 16 B per lane; the wave's 16 documents are contiguous in memory.
@@ -658,9 +674,11 @@ __global__ void __launch_bounds__(kThreads, 2) slate_pipeline_kernel(const PipeA
             if (tid < kTileDocs) dsc[tid] = 1e-3f * sc[tid];
         } else if (MODE == MODE_FUSED) {
             __syncthreads();
+            int tl = tid;                              // laundered: keeps the group geometry below from being hoisted out
+            if (DEHOIST) asm volatile("" : "+v"(tl));  // of the tile loop and spilled (see make_group)
             const int group = 4 * a.S;                 // S in {32, 64, 128}: 4 threads per document row
-            const int gid = tid / group;
-            const SlateGroup g = make_group(a.S, group, scratch + gid * (group + 32));
+            const int gid = tl / group;
+            const SlateGroup g = make_group(a.S, group, scratch + gid * (group + 32), tl);
             const int so = gid * a.S;
             const long long slate = (long long)st * (kTileDocs / a.S) + gid;
             float loss;
@@ -754,9 +772,18 @@ __global__ void __launch_bounds__(kThreads, 2) slate_pipeline_kernel(const PipeA
                 for (int T = 0; T < N::H1T; ++T)
                     *reinterpret_cast<f32x4 *>(Hs + crow * LD + 16 * T + 4 * q) = h1[T];
             }
+#ifdef LTR_STAMPS_DW
+            if (c == 0) { LTR_STAMP(10) } else { LTR_STAMP(13) }
+#endif
             __syncthreads();
+#ifdef LTR_STAMPS_DW
+            if (c == 0) { LTR_STAMP(11) } else { LTR_STAMP(14) }
+#endif
             if (!LTR_SKIP(a, 2))
                 dw_chunk<N::TW2, N::NT2, N::H1T, N::BH2, LD>(w, accW2, Ds + q * LD + d, Hs + q * LD + d);
+#ifdef LTR_STAMPS_DW
+            if (c == 0) { LTR_STAMP(12) }
+#endif
         }
         LTR_STAMP(7)
         // ---- dh1^T = W2^T dz2^T  (A = packed W2^T fragments, B = dz2 registers), then
