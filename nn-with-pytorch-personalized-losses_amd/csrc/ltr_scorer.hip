@@ -816,7 +816,10 @@ __global__ void __launch_bounds__(kThreads, 2) slate_pipeline_kernel(const PipeA
         if (MODE != MODE_FWD && XPREF && st + (int)gridDim.x < a.n_super)
             load_x_tile<N>(xn, a, (long long)(st + gridDim.x) * kTileDocs + 16 * w, lane);
         // ---- dW1 += dz1^T [x | 1]; B operand straight from the X tile in LDS.
-        if (N::H1 <= 64) {
+#ifndef LTR_DW1_SINGLE
+#define LTR_DW1_SINGLE 1    // all nets: dz1 of the whole tile staged at once (one barrier pair instead of two; -1 % on the backward)
+#endif
+        if (N::H1 <= 64 || LTR_DW1_SINGLE) {
             // dW2 is done with the two staging buffers, which are contiguous (Ds..Hs = one [128][LD] region): every
             // wave stages its dz1 tile at once, one barrier, then both 64-document halves back to back.  (-3.5 % on
             // the 136-64-32 net; on the register-bound 136-136-136 kernels the chunked form below is faster.)

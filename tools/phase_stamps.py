@@ -43,6 +43,6 @@ for name, cls in (("double", DoubleLayerNet), ("triple", TripleLayerNet)):
     epd = (ep[:, :, 1:] - ep[:, :, :-1]).reshape(-1, 7).median(0).values
     ep_names = ["fc1: start -> epoch1 dma waited", "epoch1 barrier", "epoch1 dma issue", "epoch1 lds reads + mfma", "epoch2 whole",
                 "epochs 3..8", "activation + split"]
-    rec = {"net": name, "fc1_detail": {n: round(float(v)) for n, v in zip(ep_names, epd)}, "loss_detail": {n: round(float(v)) for n, v in zip(loss_names, ld)}, "total_cycles": tot, "phases": {n: round(float(v)) for n, v in zip(NAMES, med)},
+    rec = {"net": name, "split_fc1_detail(diag build only)": {n: round(float(v)) for n, v in zip(ep_names, epd)}, "loss_detail": {n: round(float(v)) for n, v in zip(loss_names, ld)}, "total_cycles": tot, "phases": {n: round(float(v)) for n, v in zip(NAMES, med)},
            "share_pct": {n: round(100 * float(v) / tot, 1) for n, v in zip(NAMES, med)}}
     print(json.dumps(rec), flush=True)
