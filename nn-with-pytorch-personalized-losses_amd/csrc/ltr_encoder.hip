@@ -1,0 +1,1076 @@
+// ltr_encoder.hip -- the set-transformer scorer of SURVEY.md row f-3 (BASELINE config 5) on gfx950:
+// architeture/multiLayer.py:13-149 (FCModel / LTRModel / OutputLayer) and architeture/transformer.py:29-257
+// (pre-norm encoder blocks: LayerNorm -> multi-head attention over the slate -> residual, LayerNorm -> FFN ->
+// residual).  C ABI in include/ltr_encoder.h; the host side (ltr_mi355x/encoder.py) strings these launches together.
+//
+//   * ONE bf16 GEMM kernel (v_mfma_f32_16x16x32_bf16, fp32 accumulate) serves every Linear forward, input gradient
+//     and weight gradient: 128 x 128 x 64 tiles, 4 waves of 64 x 64, register-prefetched double-buffered LDS images.
+//     Operands whose contraction index is NOT the contiguous one (W in dx = dy W, both operands of dW = dy^T x) are
+//     staged as they lie in memory and read with ds_read_b64_tr_b16, so nothing is transposed in HBM.
+//   * attention: one workgroup per (slate, head); the whole S x S score row block of a 16-query tile lives in a
+//     wave's registers (S^T = K Q^T orientation: the softmax axis is register-local + two lane swaps), P^T feeds the
+//     P V product as the B operand straight from those registers.  The backward recomputes P in both orientations
+//     (query-major for dQ, key-major for dK / dV) instead of transposing through LDS.
+//   * LayerNorm / output scoring: one wave per token, fp32 statistics; parameter gradients as fixed-order
+//     per-workgroup partials (no float atomics anywhere).
+#include "../../include/ltr_encoder.h"
+#include "../../include/ltr_mi355x.h"
+#include <hip/hip_runtime.h>
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned short bf16_t;
+
+inline int status() {
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? LTR_OK : (int)e;
+}
+
+__device__ __forceinline__ f32x4 mfma_bf16(u32x4 a, u32x4 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+__device__ __forceinline__ unsigned pack_bf16(float lo, float hi) {
+    const bf16x2 p = {(__bf16)lo, (__bf16)hi};
+    return __builtin_bit_cast(unsigned, p);
+}
+__device__ __forceinline__ bf16_t to_bf16(float v) { return __builtin_bit_cast(bf16_t, (__bf16)v); }
+__device__ __forceinline__ float from_bf16(bf16_t v) { return __builtin_bit_cast(float, (unsigned)v << 16); }
+__device__ __forceinline__ float bf16_lo(unsigned p) { return __builtin_bit_cast(float, p << 16); }
+__device__ __forceinline__ float bf16_hi(unsigned p) { return __builtin_bit_cast(float, p & 0xffff0000u); }
+
+// ------------------------------------------------------------------------------------------- dropout stream
+__device__ __forceinline__ unsigned mix32(unsigned h) {
+    h ^= h >> 16; h *= 0x85EBCA6Bu; h ^= h >> 13; h *= 0xC2B2AE35u; h ^= h >> 16;
+    return h;
+}
+// 32 hash bits shared by elements 2*pair and 2*pair + 1 of stream `stream_id`
+__device__ __forceinline__ unsigned drop_word(unsigned long long seed, int stream_id, unsigned long long pair) {
+    unsigned h = (unsigned)seed ^ (0x9E3779B9u * (unsigned)(stream_id + 1));
+    h = mix32(h ^ (unsigned)pair);
+    return mix32(h ^ (unsigned)(pair >> 32) ^ (unsigned)(seed >> 32));
+}
+__host__ __device__ inline unsigned drop_threshold(float p) {
+    if (!(p > 0.f)) return 0u;
+    unsigned t = (unsigned)(p * 65536.f + 0.5f);
+    return t > 65535u ? 65535u : t;
+}
+__device__ __forceinline__ bool drop_keep(unsigned long long seed, int stream_id, unsigned long long idx, unsigned thr) {
+    const unsigned w = drop_word(seed, stream_id, idx >> 1);
+    return ((w >> (16 * (unsigned)(idx & 1))) & 0xffffu) >= thr;
+}
+// keep flags of 4 consecutive elements idx .. idx+3, idx even: bit r = element idx + r
+__device__ __forceinline__ unsigned drop_keep4(unsigned long long seed, int stream_id, unsigned long long idx, unsigned thr) {
+    const unsigned w0 = drop_word(seed, stream_id, idx >> 1), w1 = drop_word(seed, stream_id, (idx >> 1) + 1);
+    return ((w0 & 0xffffu) >= thr ? 1u : 0u) | ((w0 >> 16) >= thr ? 2u : 0u) | ((w1 & 0xffffu) >= thr ? 4u : 0u) |
+           ((w1 >> 16) >= thr ? 8u : 0u);
+}
+
+__global__ void dropout_mask_kernel(unsigned long long seed, int stream_id, long long n, unsigned thr, uint8_t *out) {
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long long)gridDim.x * blockDim.x)
+        out[e] = drop_keep(seed, stream_id, (unsigned long long)e, thr) ? 1 : 0;
+}
+
+__host__ __device__ inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
+
+// attention-probability element (slate-head bh, query q, key k) -> index in its dropout stream (Sp = S padded to 32)
+__device__ __forceinline__ unsigned long long attn_idx(int bh, int Sp, int q, int k) {
+    return ((unsigned long long)bh * Sp + q) * Sp + k;
+}
+__global__ void attn_dropout_mask_kernel(unsigned long long seed, int stream_id, int BH, int S, unsigned thr, uint8_t *out) {
+    const int Sp = round_up(S, 32);
+    const long long n = (long long)BH * S * S;
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long long)gridDim.x * blockDim.x) {
+        const int k = (int)(e % S), q = (int)((e / S) % S), bh = (int)(e / ((long long)S * S));
+        out[e] = drop_keep(seed, stream_id, attn_idx(bh, Sp, q, k), thr) ? 1 : 0;
+    }
+}
+
+__global__ void cast_bf16_kernel(const float *__restrict__ src, bf16_t *__restrict__ dst, long long n) {
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long long)gridDim.x * blockDim.x)
+        dst[e] = to_bf16(src[e]);
+}
+
+__global__ void sum_partials_kernel(const float *__restrict__ parts, int nsplit, long long n, int accumulate, float *__restrict__ out) {
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long long)gridDim.x * blockDim.x) {
+        double s = accumulate ? (double)out[e] : 0.0;
+        for (int z = 0; z < nsplit; ++z) s += (double)parts[(long long)z * n + e];
+        out[e] = (float)s;
+    }
+}
+
+// ------------------------------------------------------------------------------------------- wave helpers
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// ------------------------------------------------------------------------------------------- LayerNorm
+// One wave per token; lane l holds features l, l + 64, ...  (d <= 64 * kLnMax).
+constexpr int kLnMax = 8;
+constexpr int kLnThreads = 256;
+
+struct LnStats {
+    float mean, r, sigma;   // r = 1 / (std + eps)  (or rsqrt(var + eps)); sigma = std (annotated flavour only)
+};
+__device__ __forceinline__ LnStats ln_stats(const float (&v)[kLnMax], int d, int lane, float eps, int standard) {
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < kLnMax; ++j) s += (lane + 64 * j < d) ? v[j] : 0.f;
+    LnStats st;
+    st.mean = wave_sum(s) / (float)d;
+    float q = 0.f;
+#pragma unroll
+    for (int j = 0; j < kLnMax; ++j) {
+        const float c = (lane + 64 * j < d) ? v[j] - st.mean : 0.f;
+        q += c * c;
+    }
+    q = wave_sum(q);
+    if (standard) {
+        st.sigma = sqrtf(q / (float)d + eps);
+        st.r = 1.f / st.sigma;
+    } else {
+        st.sigma = sqrtf(q / (float)(d - 1));
+        st.r = 1.f / (st.sigma + eps);
+    }
+    return st;
+}
+
+__global__ void __launch_bounds__(kLnThreads)
+layernorm_fwd_kernel(const float *__restrict__ x, const float *__restrict__ a, const float *__restrict__ b, long long T, int d,
+                     float eps, int standard, bf16_t *__restrict__ yb, float *__restrict__ yf) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    float av[kLnMax], bv[kLnMax];
+#pragma unroll
+    for (int j = 0; j < kLnMax; ++j) {
+        const int f = lane + 64 * j;
+        av[j] = f < d ? a[f] : 0.f;
+        bv[j] = f < d ? b[f] : 0.f;
+    }
+    for (long long t = (long long)blockIdx.x * 4 + w; t < T; t += (long long)gridDim.x * 4) {
+        float v[kLnMax];
+#pragma unroll
+        for (int j = 0; j < kLnMax; ++j) v[j] = (lane + 64 * j < d) ? x[t * d + lane + 64 * j] : 0.f;
+        const LnStats st = ln_stats(v, d, lane, eps, standard);
+#pragma unroll
+        for (int j = 0; j < kLnMax; ++j) {
+            const int f = lane + 64 * j;
+            if (f < d) {
+                const float y = av[j] * (v[j] - st.mean) * st.r + bv[j];
+                if (yb) yb[t * d + f] = to_bf16(y);
+                if (yf) yf[t * d + f] = y;
+            }
+        }
+    }
+}
+
+// dx of one token through the norm, given g = dy * a per feature (in v_g) and the centred inputs.
+//   annotated:  dx_j = r (g_j - mean g) - r^2 (sum g c) c_j / ((d-1) sigma)
+//   standard:   dx_j = r (g_j - mean g - xhat_j mean(g xhat))
+__device__ __forceinline__ void ln_dx(const float (&c)[kLnMax], const float (&g)[kLnMax], const LnStats &st, int d, int lane,
+                                      int standard, float (&dx)[kLnMax]) {
+    float sg = 0.f, sgc = 0.f;
+#pragma unroll
+    for (int j = 0; j < kLnMax; ++j) {
+        sg += g[j];
+        sgc += g[j] * c[j];
+    }
+    sg = wave_sum(sg);
+    sgc = wave_sum(sgc);
+    const float mg = sg / (float)d;
+    float k2;
+    if (standard) k2 = st.r * st.r * st.r * sgc / (float)d;
+    else k2 = st.sigma > 0.f ? st.r * st.r * sgc / ((float)(d - 1) * st.sigma) : 0.f;
+#pragma unroll
+    for (int j = 0; j < kLnMax; ++j) dx[j] = (lane + 64 * j < d) ? st.r * (g[j] - mg) - k2 * c[j] : 0.f;
+}
+
+// cross-wave sum of per-thread column accumulators -> partials[blockIdx.x][col_off + f]
+__device__ __forceinline__ void block_cols_out(const float (&acc)[kLnMax], int d, float *red /* LDS [4][64*kLnMax] */,
+                                               float *__restrict__ out) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < kLnMax; ++j) red[w * 64 * kLnMax + 64 * j + lane] = acc[j];
+    __syncthreads();
+    for (int f = threadIdx.x; f < d; f += kLnThreads)
+        out[f] = (red[f] + red[64 * kLnMax + f]) + (red[2 * 64 * kLnMax + f] + red[3 * 64 * kLnMax + f]);
+}
+
+__global__ void __launch_bounds__(kLnThreads)
+layernorm_bwd_kernel(const float *__restrict__ x, const float *__restrict__ a, const float *__restrict__ dy, long long T, int d,
+                     float eps, int standard, float *__restrict__ dxo, float *__restrict__ partials) {
+    __shared__ float red[4 * 64 * kLnMax];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    float av[kLnMax], da[kLnMax], db[kLnMax];
+#pragma unroll
+    for (int j = 0; j < kLnMax; ++j) {
+        av[j] = (lane + 64 * j < d) ? a[lane + 64 * j] : 0.f;
+        da[j] = db[j] = 0.f;
+    }
+    for (long long t = (long long)blockIdx.x * 4 + w; t < T; t += (long long)gridDim.x * 4) {
+        float v[kLnMax], g[kLnMax], c[kLnMax], dx[kLnMax];
+#pragma unroll
+        for (int j = 0; j < kLnMax; ++j) {
+            const bool in = lane + 64 * j < d;
+            v[j] = in ? x[t * d + lane + 64 * j] : 0.f;
+            g[j] = in ? dy[t * d + lane + 64 * j] : 0.f;
+        }
+        const LnStats st = ln_stats(v, d, lane, eps, standard);
+#pragma unroll
+        for (int j = 0; j < kLnMax; ++j) {
+            c[j] = (lane + 64 * j < d) ? v[j] - st.mean : 0.f;
+            da[j] += g[j] * c[j] * st.r;
+            db[j] += g[j];
+            g[j] *= av[j];
+        }
+        ln_dx(c, g, st, d, lane, standard, dx);
+#pragma unroll
+        for (int j = 0; j < kLnMax; ++j)
+            if (lane + 64 * j < d) dxo[t * d + lane + 64 * j] += dx[j];
+    }
+    block_cols_out(da, d, red, partials + (long long)blockIdx.x * 2 * d);
+    block_cols_out(db, d, red, partials + (long long)blockIdx.x * 2 * d + d);
+}
+
+// scores[t] = w . LN(x[t]) + bias
+__global__ void __launch_bounds__(kLnThreads)
+score_fwd_kernel(const float *__restrict__ x, const float *__restrict__ a, const float *__restrict__ b, const float *__restrict__ wv,
+                 const float *__restrict__ bias, long long T, int d, float eps, int norm, float *__restrict__ scores) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    float aw[kLnMax], bw = 0.f;
+#pragma unroll
+    for (int j = 0; j < kLnMax; ++j) {
+        const int f = lane + 64 * j;
+        const float wj = f < d ? wv[f] : 0.f;
+        aw[j] = norm ? (f < d ? a[f] * wj : 0.f) : wj;
+        bw += (norm && f < d) ? b[f] * wj : 0.f;
+    }
+    bw = wave_sum(bw) + bias[0];
+    for (long long t = (long long)blockIdx.x * 4 + w; t < T; t += (long long)gridDim.x * 4) {
+        float v[kLnMax];
+#pragma unroll
+        for (int j = 0; j < kLnMax; ++j) v[j] = (lane + 64 * j < d) ? x[t * d + lane + 64 * j] : 0.f;
+        float s = 0.f;
+        if (norm) {
+            const LnStats st = ln_stats(v, d, lane, eps, norm == 2);
+#pragma unroll
+            for (int j = 0; j < kLnMax; ++j) s += (lane + 64 * j < d) ? aw[j] * (v[j] - st.mean) * st.r : 0.f;
+        } else {
+#pragma unroll
+            for (int j = 0; j < kLnMax; ++j) s += aw[j] * v[j];
+        }
+        s = wave_sum(s);
+        if (lane == 0) scores[t] = s + bw;
+    }
+}
+
+__global__ void __launch_bounds__(kLnThreads)
+score_bwd_kernel(const float *__restrict__ x, const float *__restrict__ a, const float *__restrict__ b, const float *__restrict__ wv,
+                 const float *__restrict__ ds, long long T, int d, float eps, int norm, float *__restrict__ dxo,
+                 float *__restrict__ partials) {
+    __shared__ float red[4 * 64 * kLnMax];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    float av[kLnMax], bv[kLnMax], wj[kLnMax], da[kLnMax], db[kLnMax], dw[kLnMax], dbias[kLnMax];
+#pragma unroll
+    for (int j = 0; j < kLnMax; ++j) {
+        const int f = lane + 64 * j;
+        wj[j] = f < d ? wv[f] : 0.f;
+        av[j] = (norm && f < d) ? a[f] : 0.f;
+        bv[j] = (norm && f < d) ? b[f] : 0.f;
+        da[j] = db[j] = dw[j] = dbias[j] = 0.f;
+    }
+    for (long long t = (long long)blockIdx.x * 4 + w; t < T; t += (long long)gridDim.x * 4) {
+        const float g0 = ds[t];
+        float v[kLnMax];
+#pragma unroll
+        for (int j = 0; j < kLnMax; ++j) v[j] = (lane + 64 * j < d) ? x[t * d + lane + 64 * j] : 0.f;
+        if (lane == 0) dbias[0] += g0;
+        if (norm) {
+            const LnStats st = ln_stats(v, d, lane, eps, norm == 2);
+            float c[kLnMax], g[kLnMax], dx[kLnMax];
+#pragma unroll
+            for (int j = 0; j < kLnMax; ++j) {
+                c[j] = (lane + 64 * j < d) ? v[j] - st.mean : 0.f;
+                const float xh = c[j] * st.r;
+                const float dyj = g0 * wj[j];                  // d loss / d y_j
+                dw[j] += g0 * (av[j] * xh + bv[j]);
+                da[j] += dyj * xh;
+                db[j] += dyj;
+                g[j] = dyj * av[j];
+            }
+            ln_dx(c, g, st, d, lane, norm == 2, dx);
+#pragma unroll
+            for (int j = 0; j < kLnMax; ++j)
+                if (lane + 64 * j < d) dxo[t * d + lane + 64 * j] = dx[j];
+        } else {
+#pragma unroll
+            for (int j = 0; j < kLnMax; ++j) {
+                dw[j] += g0 * v[j];
+                if (lane + 64 * j < d) dxo[t * d + lane + 64 * j] = g0 * wj[j];
+            }
+        }
+    }
+    float *out = partials + (long long)blockIdx.x * (3 * d + 8);
+    block_cols_out(da, d, red, out);
+    block_cols_out(db, d, red, out + d);
+    block_cols_out(dw, d, red, out + 2 * d);
+    block_cols_out(dbias, 1, red, out + 3 * d);
+}
+
+// ------------------------------------------------------------------------------------------- column sums
+// 256 threads as (row lanes) x (column chunks of W floats): every thread sums its rows' chunk, the row lanes are then
+// combined through LDS in a fixed order.
+template <int W>
+struct ColGeom {
+    int cpr, rl, c, rlanes;   // chunks per row, this thread's row lane / chunk (loops when cpr > 256), row lanes in flight
+    __device__ ColGeom(int N) {
+        cpr = N / W;
+        rlanes = cpr >= 256 ? 1 : 256 / cpr;
+        rl = cpr >= 256 ? 0 : (int)threadIdx.x / cpr;
+        c = cpr >= 256 ? (int)threadIdx.x : (int)threadIdx.x % cpr;
+    }
+    __device__ bool active() const { return rl < rlanes; }
+};
+template <int W>
+__device__ __forceinline__ void colsum_out(const ColGeom<W> &cg, const float (&acc)[W], int c, float *red /* [256][W] */,
+                                           float *__restrict__ out) {
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < W; ++k) red[threadIdx.x * W + k] = acc[k];
+    __syncthreads();
+    if (cg.rl == 0 && c < cg.cpr) {
+#pragma unroll
+        for (int k = 0; k < W; ++k) {
+            float s = 0.f;
+            for (int r = 0; r < cg.rlanes; ++r) s += red[(cg.cpr >= 256 ? (int)threadIdx.x : r * cg.cpr + c) * W + k];
+            out[c * W + k] = s;
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256)
+colsum_bf16_kernel(const bf16_t *__restrict__ y, long long T, int N, float *__restrict__ partials) {
+    __shared__ float red[256 * 8];
+    const ColGeom<8> cg(N);
+    const long long rows_per = (T + gridDim.x - 1) / gridDim.x;
+    const long long r0 = (long long)blockIdx.x * rows_per, r1 = r0 + rows_per < T ? r0 + rows_per : T;
+    for (int c0 = 0; c0 < cg.cpr; c0 += 256) {      // one pass unless N > 2048
+        const int c = c0 + cg.c;
+        float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if (cg.active() && c < cg.cpr)
+            for (long long t = r0 + cg.rl; t < r1; t += cg.rlanes) {
+                const u32x4 v = *reinterpret_cast<const u32x4 *>(y + t * N + c * 8);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    acc[2 * k] += bf16_lo(v[k]);
+                    acc[2 * k + 1] += bf16_hi(v[k]);
+                }
+            }
+        colsum_out<8>(cg, acc, c, red, partials + (long long)blockIdx.x * N);
+    }
+}
+
+__global__ void __launch_bounds__(256)
+drop_cast_colsum_kernel(const float *__restrict__ dx, long long T, int N, unsigned thr, float scale, unsigned long long seed,
+                        int stream_id, bf16_t *__restrict__ out, float *__restrict__ partials) {
+    __shared__ float red[256 * 4];
+    const ColGeom<4> cg(N);
+    const long long rows_per = (T + gridDim.x - 1) / gridDim.x;
+    const long long r0 = (long long)blockIdx.x * rows_per, r1 = r0 + rows_per < T ? r0 + rows_per : T;
+    for (int c0 = 0; c0 < cg.cpr; c0 += 256) {
+        const int c = c0 + cg.c;
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+        if (cg.active() && c < cg.cpr)
+            for (long long t = r0 + cg.rl; t < r1; t += cg.rlanes) {
+                const f32x4 v = *reinterpret_cast<const f32x4 *>(dx + t * N + c * 4);
+                const unsigned keep = thr ? drop_keep4(seed, stream_id, (unsigned long long)t * N + c * 4, thr) : 15u;
+                float o[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    // the GEMMs consume the ROUNDED value: sum that, so that db = colsum(dy) holds exactly
+                    o[k] = from_bf16(to_bf16((keep >> k) & 1u ? v[k] * scale : 0.f));
+                    acc[k] += o[k];
+                }
+                *reinterpret_cast<u32x2 *>(out + t * N + c * 4) = u32x2{pack_bf16(o[0], o[1]), pack_bf16(o[2], o[3])};
+            }
+        colsum_out<4>(cg, acc, c, red, partials + (long long)blockIdx.x * N);
+    }
+}
+
+// ------------------------------------------------------------------------------------------- GEMM
+constexpr int BM = 128, BN = 128, BK = 64;
+constexpr int LDK = BK + 8;      // k-contiguous image [rows][LDK]: 144-byte rows, conflict-free b128 / b64 fragment reads
+constexpr int LDM = BM + 16;     // k-major image [k][LDM]: 72 dwords = 8 mod 64 -> conflict-free transposed reads
+constexpr int kTileElems = BM * LDK;   // == BK * LDM == 9216 bf16
+static_assert(BM * LDK == BK * LDM && BM == BN, "both image shapes share one buffer size");
+constexpr size_t kGemmLds = (size_t)4 * kTileElems * sizeof(bf16_t);   // A, B double-buffered
+
+// ds_read_b64_tr_b16 (see ltr_bf16_split.h tr_frag): fragment of row tile t (16 rows of the GEMM's m / n axis) over
+// the 32 k rows starting at r0 of a [k][LD] image: lane (i = lane & 15, g = lane >> 4) gets row 16 t + i at
+// k = r0 + 4 g + {0..3} and r0 + 16 + 4 g + {0..3}.
+template <int LD>
+__device__ __forceinline__ u32x4 tr_frag(const bf16_t *img, int r0, int t, int lane) {
+    typedef __attribute__((address_space(3))) s16x4 *lp4;
+    const int i = lane & 15, g = lane >> 4;
+    const bf16_t *p = img + (r0 + 4 * g + (i >> 2)) * LD + 16 * t + 4 * (i & 3);
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp4)(p));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp4)(p + 16 * LD));
+    const u32x2 l2 = __builtin_bit_cast(u32x2, lo), h2 = __builtin_bit_cast(u32x2, hi);
+    return u32x4{l2[0], l2[1], h2[0], h2[1]};
+}
+
+// global -> registers: this thread's 4 16-byte pieces of the (row0, k0) tile of one operand
+template <bool KM>
+__device__ __forceinline__ void gemm_load(const bf16_t *__restrict__ P, long long ld, long long rows, long long row0, long long k0,
+                                          long long kend, int tid, u32x4 (&r)[4]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int p = tid + 256 * i;
+        const u32x4 z = {0u, 0u, 0u, 0u};
+        if (KM) {
+            const int kr = p >> 4, ch = p & 15;
+            const long long k = k0 + kr, m = row0 + 8 * ch;
+            r[i] = (k < kend && m < rows) ? *reinterpret_cast<const u32x4 *>(P + k * ld + m) : z;
+        } else {
+            const int row = p >> 3, ch = p & 7;
+            const long long m = row0 + row, k = k0 + 8 * ch;
+            r[i] = (m < rows && k < kend) ? *reinterpret_cast<const u32x4 *>(P + m * ld + k) : z;
+        }
+    }
+}
+template <bool KM>
+__device__ __forceinline__ void gemm_store(bf16_t *img, int tid, const u32x4 (&r)[4]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int p = tid + 256 * i;
+        if (KM) *reinterpret_cast<u32x4 *>(img + (p >> 4) * LDM + 8 * (p & 15)) = r[i];
+        else *reinterpret_cast<u32x4 *>(img + (p >> 3) * LDK + 8 * (p & 7)) = r[i];
+    }
+}
+// fragment of 16-row tile `t` of the image for the 32-wide k sub-step kk.  SPLIT: the k <-> slot assignment of the
+// transposed reads (4g.., 16+4g..), otherwise 8 consecutive k per lane group.
+template <bool KM, bool SPLIT>
+__device__ __forceinline__ u32x4 gemm_frag(const bf16_t *img, int t, int kk, int lane) {
+    if (KM) return tr_frag<LDM>(img, 32 * kk, t, lane);
+    const int i = lane & 15, g = lane >> 4;
+    const bf16_t *row = img + (16 * t + i) * LDK + 32 * kk;
+    if (SPLIT) {
+        const u32x2 lo = *reinterpret_cast<const u32x2 *>(row + 4 * g), hi = *reinterpret_cast<const u32x2 *>(row + 16 + 4 * g);
+        return u32x4{lo[0], lo[1], hi[0], hi[1]};
+    }
+    return *reinterpret_cast<const u32x4 *>(row + 8 * g);
+}
+
+template <bool AKM, bool BKM>
+__global__ void __launch_bounds__(256, 2) gemm_bf16_kernel(ltr_gemm_desc g) {
+    extern __shared__ __attribute__((aligned(16))) bf16_t smem[];
+    constexpr bool SPLIT = AKM || BKM;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, wm = w >> 1, wn = w & 1;
+    const long long m0 = (long long)blockIdx.y * BM, n0 = (long long)blockIdx.x * BN;
+    // split-K slice of this workgroup (whole BK steps)
+    const long long ksteps = (g.K + BK - 1) / BK, per = (ksteps + g.splits - 1) / g.splits;
+    const long long kbeg = (long long)blockIdx.z * per * BK;
+    const long long kend = kbeg + per * BK < g.K ? kbeg + per * BK : g.K;
+    const int nk = kend > kbeg ? (int)((kend - kbeg + BK - 1) / BK) : 0;
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    u32x4 ra[4], rb[4];
+    if (nk > 0) {
+        gemm_load<AKM>(g.A, g.lda, g.M, m0, kbeg, kend, tid, ra);
+        gemm_load<BKM>(g.B, g.ldb, g.N, n0, kbeg, kend, tid, rb);
+        gemm_store<AKM>(smem, tid, ra);
+        gemm_store<BKM>(smem + kTileElems, tid, rb);
+    }
+    __syncthreads();
+    for (int t = 0; t < nk; ++t) {
+        const bf16_t *As = smem + (t & 1) * 2 * kTileElems, *Bs = As + kTileElems;
+        if (t + 1 < nk) {
+            gemm_load<AKM>(g.A, g.lda, g.M, m0, kbeg + (long long)(t + 1) * BK, kend, tid, ra);
+            gemm_load<BKM>(g.B, g.ldb, g.N, n0, kbeg + (long long)(t + 1) * BK, kend, tid, rb);
+        }
+#pragma unroll
+        for (int kk = 0; kk < BK / 32; ++kk) {
+            u32x4 af[4], bf[4];
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi) af[mi] = gemm_frag<AKM, SPLIT>(As, wm * 4 + mi, kk, lane);
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni) bf[ni] = gemm_frag<BKM, SPLIT>(Bs, wn * 4 + ni, kk, lane);
+            // operands swapped: the accumulator tile is C^T (lane & 15 = m, registers = 4 consecutive n)
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = mfma_bf16(bf[ni], af[mi], acc[mi][ni]);
+        }
+        if (t + 1 < nk) {
+            bf16_t *An = smem + ((t + 1) & 1) * 2 * kTileElems;
+            gemm_store<AKM>(An, tid, ra);
+            gemm_store<BKM>(An + kTileElems, tid, rb);
+        }
+        __syncthreads();
+    }
+
+    // epilogue
+    const int j = lane & 15, q = lane >> 4;
+    const bool raw = g.splits > 1;
+    float *Cf = raw ? g.Cf + (long long)blockIdx.z * g.M * g.ldc : g.Cf;
+    const unsigned thr = raw ? 0u : drop_threshold(g.drop_p);
+    const float keep_scale = thr ? 1.f / (1.f - g.drop_p) : 1.f;
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi) {
+        const long long m = m0 + wm * 64 + mi * 16 + j;
+        if (m >= g.M) continue;
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) {
+            const long long n = n0 + wn * 64 + ni * 16 + 4 * q;
+            if (n >= g.N) continue;
+            f32x4 v = acc[mi][ni];
+            if (!raw) {
+                if (g.bias) v += *reinterpret_cast<const f32x4 *>(g.bias + n);
+                if (g.relu) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+                }
+                if (g.gate) {
+                    const u32x2 gt = *reinterpret_cast<const u32x2 *>(g.gate + m * g.ldc + n);
+                    v[0] = bf16_lo(gt[0]) > 0.f ? v[0] * g.gate_scale : 0.f;
+                    v[1] = bf16_hi(gt[0]) > 0.f ? v[1] * g.gate_scale : 0.f;
+                    v[2] = bf16_lo(gt[1]) > 0.f ? v[2] * g.gate_scale : 0.f;
+                    v[3] = bf16_hi(gt[1]) > 0.f ? v[3] * g.gate_scale : 0.f;
+                }
+                if (thr) {
+                    const unsigned keep = drop_keep4(g.seed, g.drop_stream, (unsigned long long)m * g.N + n, thr);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = (keep >> r) & 1u ? v[r] * keep_scale : 0.f;
+                }
+                if (g.residual) v += *reinterpret_cast<const f32x4 *>(g.residual + m * g.ldc + n);
+            }
+            if (Cf) *reinterpret_cast<f32x4 *>(Cf + m * g.ldc + n) = v;
+            if (!raw && g.Cb) *reinterpret_cast<u32x2 *>(g.Cb + m * g.ldc + n) = u32x2{pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3])};
+        }
+    }
+}
+
+template <bool AKM, bool BKM>
+int launch_gemm(const ltr_gemm_desc &g, hipStream_t stream) {
+    static bool attr_done[64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = -1;
+    if (dev < 0 || !attr_done[dev]) {
+        hipError_t e = hipFuncSetAttribute((const void *)gemm_bf16_kernel<AKM, BKM>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           (int)kGemmLds);
+        if (e != hipSuccess) return (int)e;
+        if (dev >= 0) attr_done[dev] = true;
+    }
+    const dim3 grid((unsigned)((g.N + BN - 1) / BN), (unsigned)((g.M + BM - 1) / BM), (unsigned)g.splits);
+    hipLaunchKernelGGL((gemm_bf16_kernel<AKM, BKM>), grid, dim3(256), kGemmLds, stream, g);
+    return status();
+}
+
+// ------------------------------------------------------------------------------------------- attention
+constexpr int kAttThreads = 256;
+constexpr int kDkPad = 32;              // head dimension padded to one MFMA k step
+constexpr int kRowLd = kDkPad + 8;      // [token][d] images: 80-byte rows, conflict-free b128 row fragments
+// [d][token] images (V^T, K^T, Q^T, dO^T): row stride = 4 dwords mod 64 -> the two 8-byte reads per fragment
+// (tokens 4g.., 16+4g..) of 16 rows x 2 lane groups cover all 64 banks
+__host__ __device__ inline int tr_ld(int Sp) { return ((Sp / 2 + 59) / 64 * 64 + 4) * 2; }
+
+struct AttArgs {
+    const bf16_t *qkv;
+    const bf16_t *dctx;
+    const uint8_t *mask;
+    bf16_t *out;          // fwd: ctx [T][d]; bwd: dqkv [T][3d]
+    int B, S, h, dk;
+    float drop_p;
+    unsigned long long seed;
+    int stream_id;
+};
+
+// 8 consecutive head features d0 .. d0+7 of one token row (zero beyond dk / for missing rows)
+__device__ __forceinline__ u32x4 load8(const bf16_t *row, int d0, int dk, bool vec, bool valid) {
+    u32x4 r = {0u, 0u, 0u, 0u};
+    if (!valid) return r;
+    if (vec) {
+        if (d0 + 8 <= dk) r = *reinterpret_cast<const u32x4 *>(row + d0);
+        return r;
+    }
+    unsigned short e[8];
+#pragma unroll
+    for (int x = 0; x < 8; ++x) e[x] = d0 + x < dk ? row[d0 + x] : (unsigned short)0;
+    return u32x4{(unsigned)e[0] | ((unsigned)e[1] << 16), (unsigned)e[2] | ((unsigned)e[3] << 16),
+                 (unsigned)e[4] | ((unsigned)e[5] << 16), (unsigned)e[6] | ((unsigned)e[7] << 16)};
+}
+// 4 consecutive head features d0..d0+3 of an accumulator -> bf16 row (guarded)
+__device__ __forceinline__ void store4(bf16_t *row, int d0, int dk, bool vec, const f32x4 &v) {
+    if (vec && d0 + 4 <= dk) {
+        *reinterpret_cast<u32x2 *>(row + d0) = u32x2{pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3])};
+        return;
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+        if (d0 + r < dk) row[d0 + r] = to_bf16(v[r]);
+}
+
+// stage `which` (0 Q, 1 K, 2 V of qkv; 3 = dctx) of slate b / head hd: row image [Sp][kRowLd] and/or transposed image
+// [32][ldt].  All threads of the workgroup.
+__device__ __forceinline__ void stage_head(const AttArgs &a, int b, int hd, int which, int Sp, bf16_t *rows, bf16_t *tr, int ldt) {
+    const int d = a.h * a.dk;
+    const bool vec = a.dk % 8 == 0;
+    const bf16_t *base = which < 3 ? a.qkv + (long long)b * a.S * 3 * d + which * d + hd * a.dk
+                                   : a.dctx + (long long)b * a.S * d + hd * a.dk;
+    const long long ld = which < 3 ? 3 * d : d;
+    for (int e = threadIdx.x; e < Sp * 4; e += kAttThreads) {
+        const int tok = e >> 2, ch = e & 3;
+        const u32x4 v = load8(base + tok * ld, 8 * ch, a.dk, vec, tok < a.S);
+        if (rows) *reinterpret_cast<u32x4 *>(rows + tok * kRowLd + 8 * ch) = v;
+        if (tr) {
+#pragma unroll
+            for (int x = 0; x < 4; ++x) {
+                tr[(8 * ch + 2 * x) * ldt + tok] = (bf16_t)(v[x] & 0xffffu);
+                tr[(8 * ch + 2 * x + 1) * ldt + tok] = (bf16_t)(v[x] >> 16);
+            }
+        }
+    }
+}
+
+// row fragment (A or B operand with the token on lane & 15, 8 consecutive d per lane group)
+__device__ __forceinline__ u32x4 row_frag(const bf16_t *rows, int tile, int lane) {
+    return *reinterpret_cast<const u32x4 *>(rows + (16 * tile + (lane & 15)) * kRowLd + 8 * (lane >> 4));
+}
+// fragment of a [d][token] image: d = 16 dt + (lane & 15), tokens 32 u + 4 g + {0..3} and 32 u + 16 + 4 g + {0..3}
+__device__ __forceinline__ u32x4 col_frag(const bf16_t *tr, int ldt, int dt, int u, int lane) {
+    const bf16_t *p = tr + (16 * dt + (lane & 15)) * ldt + 32 * u + 4 * (lane >> 4);
+    const u32x2 lo = *reinterpret_cast<const u32x2 *>(p), hi = *reinterpret_cast<const u32x2 *>(p + 16);
+    return u32x4{lo[0], lo[1], hi[0], hi[1]};
+}
+// reduce over the 4 lane groups holding one query (lanes j, j+16, j+32, j+48)
+__device__ __forceinline__ float quad_sum(float v) {
+    v += __shfl_xor(v, 16, 64);
+    return v + __shfl_xor(v, 32, 64);
+}
+__device__ __forceinline__ float quad_max(float v) {
+    v = fmaxf(v, __shfl_xor(v, 16, 64));
+    return fmaxf(v, __shfl_xor(v, 32, 64));
+}
+
+// Softmax probabilities of one 16-query tile in the S^T orientation: st[kt][r] = score of key 16 kt + 4 g + r for
+// query (lane & 15), in place -> p; returns row max / 1/sum through m, inv.
+template <int KTMAX>
+__device__ __forceinline__ void softmax_tile(f32x4 (&st)[KTMAX], int KT, const uint8_t *maskS, float scale, int g, float &m, float &inv) {
+    m = -INFINITY;
+#pragma unroll
+    for (int kt = 0; kt < KTMAX; ++kt)
+        if (kt < KT) {
+            const unsigned mk = *reinterpret_cast<const unsigned *>(maskS + 16 * kt + 4 * g);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                st[kt][r] = (mk >> (8 * r)) & 0xffu ? -INFINITY : st[kt][r] * scale;
+                m = fmaxf(m, st[kt][r]);
+            }
+        }
+    m = quad_max(m);
+    if (m == -INFINITY) m = 0.f;
+    float l = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < KTMAX; ++kt)
+        if (kt < KT) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                st[kt][r] = __expf(st[kt][r] - m);
+                l += st[kt][r];
+            }
+        }
+    l = quad_sum(l);
+    inv = l > 0.f ? 1.f / l : 0.f;
+#pragma unroll
+    for (int kt = 0; kt < KTMAX; ++kt)
+        if (kt < KT) st[kt] *= inv;
+}
+
+template <int KTMAX>
+__global__ void __launch_bounds__(kAttThreads) attention_fwd_kernel(AttArgs a) {
+    extern __shared__ __attribute__((aligned(16))) bf16_t smem[];
+    const int Sp = round_up(a.S, 32), KT = Sp / 16, ldt = tr_ld(Sp);
+    bf16_t *Kimg = smem, *VT = Kimg + Sp * kRowLd;
+    uint8_t *maskS = reinterpret_cast<uint8_t *>(VT + kDkPad * ldt);
+    const int b = blockIdx.x / a.h, hd = blockIdx.x % a.h, d = a.h * a.dk;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, j = lane & 15, g = lane >> 4;
+    const bool vec = a.dk % 8 == 0;
+    stage_head(a, b, hd, 1, Sp, Kimg, nullptr, 0);
+    stage_head(a, b, hd, 2, Sp, nullptr, VT, ldt);
+    for (int k = threadIdx.x; k < Sp; k += kAttThreads) maskS[k] = k >= a.S || (a.mask && a.mask[(long long)b * a.S + k] == 1) ? 1 : 0;
+    __syncthreads();
+    const float scale = 1.f / sqrtf((float)a.dk);
+    const unsigned thr = drop_threshold(a.drop_p);
+    const float ks = thr ? 1.f / (1.f - a.drop_p) : 1.f;
+    for (int qt = w; qt * 16 < a.S; qt += kAttThreads / 64) {
+        const int query = 16 * qt + j;
+        const u32x4 qf = load8(a.qkv + ((long long)b * a.S + query) * 3 * d + hd * a.dk, 8 * g, a.dk, vec, query < a.S);
+        f32x4 st[KTMAX];
+#pragma unroll
+        for (int kt = 0; kt < KTMAX; ++kt)
+            if (kt < KT) st[kt] = mfma_bf16(row_frag(Kimg, kt, lane), qf, f32x4{0.f, 0.f, 0.f, 0.f});
+        float m, inv;
+        softmax_tile<KTMAX>(st, KT, maskS, scale, g, m, inv);
+        f32x4 o[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+        for (int u = 0; u < KTMAX / 2; ++u)
+            if (2 * u < KT) {
+                unsigned pk[4];
+#pragma unroll
+                for (int half = 0; half < 2; ++half) {
+                    f32x4 p = st[2 * u + half];
+                    if (thr) {
+                        const unsigned keep = drop_keep4(a.seed, a.stream_id, attn_idx(blockIdx.x, Sp, query, 32 * u + 16 * half + 4 * g), thr);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) p[r] = (keep >> r) & 1u ? p[r] * ks : 0.f;
+                    }
+                    pk[2 * half] = pack_bf16(p[0], p[1]);
+                    pk[2 * half + 1] = pack_bf16(p[2], p[3]);
+                }
+                const u32x4 pf = {pk[0], pk[1], pk[2], pk[3]};
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt) o[dt] = mfma_bf16(col_frag(VT, ldt, dt, u, lane), pf, o[dt]);
+            }
+        if (query < a.S) {
+            bf16_t *row = a.out + ((long long)b * a.S + query) * d + hd * a.dk;
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt) store4(row, 16 * dt + 4 * g, a.dk, a.dk % 4 == 0, o[dt]);
+        }
+    }
+}
+
+inline size_t att_fwd_lds(int S) {
+    const int Sp = round_up(S, 32);
+    return (size_t)(Sp * kRowLd + kDkPad * tr_ld(Sp)) * sizeof(bf16_t) + (size_t)Sp;
+}
+
+// Backward.  Phase A (query-major, like the forward): D_q = sum_k dP P, dS^T -> dQ; row statistics to LDS.
+// Phase B (key-major): P and dS recomputed as [query][key] tiles -> dV^T = dO^T Pd, dK^T = Q^T dS.
+template <int KTMAX>
+__global__ void __launch_bounds__(kAttThreads) attention_bwd_kernel(AttArgs a) {
+    extern __shared__ __attribute__((aligned(16))) bf16_t smem[];
+    const int Sp = round_up(a.S, 32), KT = Sp / 16, ldt = tr_ld(Sp);
+    // phase A images: K rows, V rows, K^T;  phase B images: Q rows, dO rows, Q^T, dO^T (same memory)
+    bf16_t *img0 = smem, *img1 = img0 + Sp * kRowLd, *tr0 = img1 + Sp * kRowLd, *tr1 = tr0 + kDkPad * ldt;
+    f32x4 *stats = reinterpret_cast<f32x4 *>(tr1 + kDkPad * ldt);       // [Sp] (row max, 1/sum, D, -)
+    uint8_t *maskS = reinterpret_cast<uint8_t *>(stats + Sp);
+    const int b = blockIdx.x / a.h, hd = blockIdx.x % a.h, d = a.h * a.dk;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, j = lane & 15, g = lane >> 4;
+    const bool vec = a.dk % 8 == 0;
+    const float scale = 1.f / sqrtf((float)a.dk);
+    const unsigned thr = drop_threshold(a.drop_p);
+    const float ks = thr ? 1.f / (1.f - a.drop_p) : 1.f;
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+
+    stage_head(a, b, hd, 1, Sp, img0, tr0, ldt);
+    stage_head(a, b, hd, 2, Sp, img1, nullptr, 0);
+    for (int k = threadIdx.x; k < Sp; k += kAttThreads) {
+        maskS[k] = k >= a.S || (a.mask && a.mask[(long long)b * a.S + k] == 1) ? 1 : 0;
+        stats[k] = zero;
+    }
+    __syncthreads();
+    for (int qt = w; qt * 16 < a.S; qt += kAttThreads / 64) {
+        const int query = 16 * qt + j;
+        const long long tok = (long long)b * a.S + query;
+        const u32x4 qf = load8(a.qkv + tok * 3 * d + hd * a.dk, 8 * g, a.dk, vec, query < a.S);
+        const u32x4 dof = load8(a.dctx + tok * d + hd * a.dk, 8 * g, a.dk, vec, query < a.S);
+        f32x4 st[KTMAX];
+#pragma unroll
+        for (int kt = 0; kt < KTMAX; ++kt)
+            if (kt < KT) st[kt] = mfma_bf16(row_frag(img0, kt, lane), qf, zero);
+        float m, inv;
+        softmax_tile<KTMAX>(st, KT, maskS, scale, g, m, inv);
+        // D = sum_k dP P  (dP = keep ? dPd / (1-p) : 0, dPd^T = V dO^T)
+        float D = 0.f;
+        unsigned keepbits[KTMAX / 8 > 0 ? KTMAX / 8 : 1];   // 4 bits per key tile
+#pragma unroll
+        for (int kt = 0; kt < KTMAX; ++kt)
+            if (kt < KT) {
+                const f32x4 dp = mfma_bf16(row_frag(img1, kt, lane), dof, zero);
+                const unsigned keep = thr ? drop_keep4(a.seed, a.stream_id, attn_idx(blockIdx.x, Sp, query, 16 * kt + 4 * g), thr) : 15u;
+                if ((kt & 7) == 0) keepbits[kt >> 3] = 0u;
+                keepbits[kt >> 3] |= keep << (4 * (kt & 7));
+#pragma unroll
+                for (int r = 0; r < 4; ++r) D += (keep >> r) & 1u ? dp[r] * ks * st[kt][r] : 0.f;
+            }
+        D = quad_sum(D);
+        if (g == 0 && query < a.S) stats[query] = f32x4{m, inv, D, 0.f};
+        f32x4 o[2] = {zero, zero};
+#pragma unroll
+        for (int u = 0; u < KTMAX / 2; ++u)
+            if (2 * u < KT) {
+                unsigned pk[4];
+#pragma unroll
+                for (int half = 0; half < 2; ++half) {
+                    const int kt = 2 * u + half;
+                    const f32x4 dp = mfma_bf16(row_frag(img1, kt, lane), dof, zero);
+                    const unsigned keep = (keepbits[kt >> 3] >> (4 * (kt & 7))) & 15u;
+                    f32x4 ds;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) ds[r] = st[kt][r] * (((keep >> r) & 1u ? dp[r] * ks : 0.f) - D) * scale;
+                    pk[2 * half] = pack_bf16(ds[0], ds[1]);
+                    pk[2 * half + 1] = pack_bf16(ds[2], ds[3]);
+                }
+                const u32x4 dsf = {pk[0], pk[1], pk[2], pk[3]};
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt) o[dt] = mfma_bf16(col_frag(tr0, ldt, dt, u, lane), dsf, o[dt]);
+            }
+        if (query < a.S) {
+            bf16_t *row = a.out + tok * 3 * d + hd * a.dk;
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt) store4(row, 16 * dt + 4 * g, a.dk, a.dk % 4 == 0, o[dt]);
+        }
+    }
+    __syncthreads();
+    stage_head(a, b, hd, 0, Sp, img0, tr0, ldt);
+    stage_head(a, b, hd, 3, Sp, img1, tr1, ldt);
+    __syncthreads();
+    for (int kt = w; kt * 16 < a.S; kt += kAttThreads / 64) {
+        const int key = 16 * kt + j;
+        const long long tok = (long long)b * a.S + key;
+        const u32x4 kf = load8(a.qkv + tok * 3 * d + d + hd * a.dk, 8 * g, a.dk, vec, key < a.S);
+        const u32x4 vf = load8(a.qkv + tok * 3 * d + 2 * d + hd * a.dk, 8 * g, a.dk, vec, key < a.S);
+        const bool masked = maskS[key < Sp ? key : 0] != 0;
+        f32x4 dv[2] = {zero, zero}, dkk[2] = {zero, zero};
+        for (int u = 0; u < KT / 2; ++u) {
+            unsigned pk[4], dk4[4];
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                const int qt = 2 * u + half;
+                const f32x4 s = mfma_bf16(row_frag(img0, qt, lane), kf, zero);      // S[query 16 qt + 4 g + r][key]
+                const f32x4 dpd = mfma_bf16(row_frag(img1, qt, lane), vf, zero);    // dPd[query][key]
+                f32x4 pd, ds;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int query = 16 * qt + 4 * g + r;
+                    const f32x4 sq = stats[query];
+                    const float p = masked ? 0.f : __expf(s[r] * scale - sq[0]) * sq[1];
+                    const bool keep = thr ? drop_keep(a.seed, a.stream_id, attn_idx(blockIdx.x, Sp, query, key), thr) : true;
+                    pd[r] = keep ? p * ks : 0.f;
+                    ds[r] = p * ((keep ? dpd[r] * ks : 0.f) - sq[2]) * scale;
+                }
+                pk[2 * half] = pack_bf16(pd[0], pd[1]);
+                pk[2 * half + 1] = pack_bf16(pd[2], pd[3]);
+                dk4[2 * half] = pack_bf16(ds[0], ds[1]);
+                dk4[2 * half + 1] = pack_bf16(ds[2], ds[3]);
+            }
+            const u32x4 pf = {pk[0], pk[1], pk[2], pk[3]}, dsf = {dk4[0], dk4[1], dk4[2], dk4[3]};
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt) {
+                dv[dt] = mfma_bf16(col_frag(tr1, ldt, dt, u, lane), pf, dv[dt]);
+                dkk[dt] = mfma_bf16(col_frag(tr0, ldt, dt, u, lane), dsf, dkk[dt]);
+            }
+        }
+        if (key < a.S) {
+            bf16_t *row = a.out + tok * 3 * d + hd * a.dk;
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt) {
+                store4(row + d, 16 * dt + 4 * g, a.dk, a.dk % 4 == 0, dkk[dt]);
+                store4(row + 2 * d, 16 * dt + 4 * g, a.dk, a.dk % 4 == 0, dv[dt]);
+            }
+        }
+    }
+}
+
+inline size_t att_bwd_lds(int S) {
+    const int Sp = round_up(S, 32);
+    return (size_t)(2 * Sp * kRowLd + 2 * kDkPad * tr_ld(Sp)) * sizeof(bf16_t) + (size_t)Sp * 16 + (size_t)Sp;
+}
+
+template <class K>
+int set_lds_attr(K kernel, size_t lds, bool (&done)[64]) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = -1;
+    if (dev < 0 || !done[dev]) {
+        hipError_t e = hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return (int)e;
+        if (dev >= 0) done[dev] = true;
+    }
+    (void)lds;
+    return 0;
+}
+
+int check_att(const uint16_t *qkv, const void *other, int B, int S, int h, int dk, float p) {
+    if (!qkv || !other) return LTR_ERR_NULL;
+    if (B < 0 || S < 1 || S > 512 || h < 1 || dk < 1 || dk > kDkPad) return LTR_ERR_SHAPE;
+    if ((h * dk) % 8 != 0) return LTR_ERR_SHAPE;
+    if (!(p >= 0.f) || p >= 1.f) return LTR_ERR_PARAM;
+    if (((uintptr_t)qkv & 15u) || ((uintptr_t)other & 15u)) return LTR_ERR_ALIGN;
+    return 0;
+}
+
+inline int elt_grid(int64_t n, int threads, int cap = 256 * 8) {
+    int64_t b = (n + threads - 1) / threads;
+    return (int)(b < 1 ? 1 : (b > cap ? cap : b));
+}
+
+}  // namespace
+
+extern "C" {
+
+int ltr_enc_cast_bf16(const float *src, uint16_t *dst, int64_t n, void *stream) {
+    if (!src || !dst) return LTR_ERR_NULL;
+    if (n < 0) return LTR_ERR_SHAPE;
+    if (n == 0) return LTR_OK;
+    hipLaunchKernelGGL(cast_bf16_kernel, dim3(elt_grid(n, 256)), dim3(256), 0, (hipStream_t)stream, src, dst, (long long)n);
+    return status();
+}
+
+int ltr_enc_dropout_mask(uint64_t seed, int stream_id, int64_t n, float p, uint8_t *out, void *stream) {
+    if (!out) return LTR_ERR_NULL;
+    if (n < 0) return LTR_ERR_SHAPE;
+    if (!(p >= 0.f) || p >= 1.f) return LTR_ERR_PARAM;
+    if (n == 0) return LTR_OK;
+    hipLaunchKernelGGL(dropout_mask_kernel, dim3(elt_grid(n, 256)), dim3(256), 0, (hipStream_t)stream, (unsigned long long)seed,
+                       stream_id, (long long)n, drop_threshold(p), out);
+    return status();
+}
+
+int ltr_enc_attn_dropout_mask(uint64_t seed, int stream_id, int B, int S, int h, float p, uint8_t *out, void *stream) {
+    if (!out) return LTR_ERR_NULL;
+    if (B < 0 || S < 1 || h < 1) return LTR_ERR_SHAPE;
+    if (!(p >= 0.f) || p >= 1.f) return LTR_ERR_PARAM;
+    if (B == 0) return LTR_OK;
+    hipLaunchKernelGGL(attn_dropout_mask_kernel, dim3(elt_grid((int64_t)B * h * S * S, 256)), dim3(256), 0, (hipStream_t)stream,
+                       (unsigned long long)seed, stream_id, B * h, S, drop_threshold(p), out);
+    return status();
+}
+
+int ltr_enc_sum_partials(const float *parts, int nsplit, int64_t n, int accumulate, float *out, void *stream) {
+    if (!parts || !out) return LTR_ERR_NULL;
+    if (nsplit < 1 || n < 0) return LTR_ERR_SHAPE;
+    if (n == 0) return LTR_OK;
+    hipLaunchKernelGGL(sum_partials_kernel, dim3(elt_grid(n, 256)), dim3(256), 0, (hipStream_t)stream, parts, nsplit, (long long)n,
+                       accumulate, out);
+    return status();
+}
+
+int ltr_enc_layernorm_fwd(const float *x, const float *a, const float *b, int64_t T, int d, float eps, int standard,
+                          uint16_t *y_bf16, float *y_f32, void *stream) {
+    if (!x || !a || !b || (!y_bf16 && !y_f32)) return LTR_ERR_NULL;
+    if (T < 0 || d < 2 || d > 64 * kLnMax) return LTR_ERR_SHAPE;
+    if (T == 0) return LTR_OK;
+    hipLaunchKernelGGL(layernorm_fwd_kernel, dim3(elt_grid(T, 4)), dim3(kLnThreads), 0, (hipStream_t)stream, x, a, b, (long long)T, d,
+                       eps, standard, y_bf16, y_f32);
+    return status();
+}
+
+int ltr_enc_layernorm_bwd(const float *x, const float *a, const float *dy, int64_t T, int d, float eps, int standard,
+                          float *dx, float *partials, int nblk, void *stream) {
+    if (!x || !a || !dy || !dx || !partials) return LTR_ERR_NULL;
+    if (T < 0 || d < 2 || d > 64 * kLnMax || nblk < 1 || nblk > 65535) return LTR_ERR_SHAPE;
+    hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(nblk), dim3(kLnThreads), 0, (hipStream_t)stream, x, a, dy, (long long)T, d, eps,
+                       standard, dx, partials);
+    return status();
+}
+
+int ltr_enc_gemm_bf16(const ltr_gemm_desc *desc, void *stream) {
+    if (!desc || !desc->A || !desc->B || (!desc->Cf && !desc->Cb)) return LTR_ERR_NULL;
+    const ltr_gemm_desc &g = *desc;
+    if (g.M < 0 || g.N < 1 || g.K < 1 || g.splits < 1 || g.splits > 1024) return LTR_ERR_SHAPE;
+    if (g.M == 0) return LTR_OK;
+    if (g.N % 8 || g.lda % 8 || g.ldb % 8 || g.ldc % 4 || g.ldc < g.N) return LTR_ERR_SHAPE;
+    if (!g.a_kmajor && g.K % 8) return LTR_ERR_SHAPE;
+    if (!g.b_kmajor && g.K % 8) return LTR_ERR_SHAPE;
+    if (g.a_kmajor && g.M % 8) return LTR_ERR_SHAPE;
+    if (g.splits > 1 && !g.Cf) return LTR_ERR_NULL;
+    if (!(g.drop_p >= 0.f) || g.drop_p >= 1.f) return LTR_ERR_PARAM;
+    if (((uintptr_t)g.A & 15u) || ((uintptr_t)g.B & 15u) || ((uintptr_t)g.Cf & 15u) || ((uintptr_t)g.Cb & 7u) ||
+        ((uintptr_t)g.bias & 15u) || ((uintptr_t)g.residual & 15u) || ((uintptr_t)g.gate & 7u))
+        return LTR_ERR_ALIGN;
+    if ((g.M + BM - 1) / BM > 65535) return LTR_ERR_SHAPE;
+    hipStream_t s = (hipStream_t)stream;
+    if (g.a_kmajor) return g.b_kmajor ? launch_gemm<true, true>(g, s) : launch_gemm<true, false>(g, s);
+    return g.b_kmajor ? launch_gemm<false, true>(g, s) : launch_gemm<false, false>(g, s);
+}
+
+int ltr_enc_colsum_bf16(const uint16_t *y, int64_t T, int N, float *partials, int nblk, void *stream) {
+    if (!y || !partials) return LTR_ERR_NULL;
+    if (T < 0 || N < 8 || N % 8 || nblk < 1) return LTR_ERR_SHAPE;
+    if ((uintptr_t)y & 15u) return LTR_ERR_ALIGN;
+    hipLaunchKernelGGL(colsum_bf16_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)stream, y, (long long)T, N, partials);
+    return status();
+}
+
+int ltr_enc_drop_cast_colsum(const float *dx, int64_t T, int N, float p, uint64_t seed, int stream_id, uint16_t *out,
+                             float *partials, int nblk, void *stream) {
+    if (!dx || !out || !partials) return LTR_ERR_NULL;
+    if (T < 0 || N < 8 || N % 8 || nblk < 1) return LTR_ERR_SHAPE;
+    if (!(p >= 0.f) || p >= 1.f) return LTR_ERR_PARAM;
+    if (((uintptr_t)dx & 15u) || ((uintptr_t)out & 7u)) return LTR_ERR_ALIGN;
+    const unsigned thr = drop_threshold(p);
+    hipLaunchKernelGGL(drop_cast_colsum_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)stream, dx, (long long)T, N, thr,
+                       thr ? 1.f / (1.f - p) : 1.f, (unsigned long long)seed, stream_id, out, partials);
+    return status();
+}
+
+int ltr_enc_attention_fwd(const uint16_t *qkv, const uint8_t *mask, int B, int S, int h, int dk, float drop_p,
+                          uint64_t seed, int stream_id, uint16_t *ctx, void *stream) {
+    if (int rc = check_att(qkv, ctx, B, S, h, dk, drop_p)) return rc;
+    if (B == 0) return LTR_OK;
+    AttArgs a{qkv, nullptr, mask, ctx, B, S, h, dk, drop_p, (unsigned long long)seed, stream_id};
+    const size_t lds = att_fwd_lds(S);
+    static bool done16[64] = {}, done32[64] = {};
+    if (S <= 256) {
+        if (int rc = set_lds_attr(attention_fwd_kernel<16>, lds, done16)) return rc;
+        hipLaunchKernelGGL(attention_fwd_kernel<16>, dim3(B * h), dim3(kAttThreads), lds, (hipStream_t)stream, a);
+    } else {
+        if (int rc = set_lds_attr(attention_fwd_kernel<32>, lds, done32)) return rc;
+        hipLaunchKernelGGL(attention_fwd_kernel<32>, dim3(B * h), dim3(kAttThreads), lds, (hipStream_t)stream, a);
+    }
+    return status();
+}
+
+int ltr_enc_attention_bwd(const uint16_t *qkv, const uint16_t *dctx, const uint8_t *mask, int B, int S, int h, int dk,
+                          float drop_p, uint64_t seed, int stream_id, uint16_t *dqkv, void *stream) {
+    if (!dctx) return LTR_ERR_NULL;
+    if (int rc = check_att(qkv, dqkv, B, S, h, dk, drop_p)) return rc;
+    if ((uintptr_t)dctx & 15u) return LTR_ERR_ALIGN;
+    if (B == 0) return LTR_OK;
+    AttArgs a{qkv, dctx, mask, dqkv, B, S, h, dk, drop_p, (unsigned long long)seed, stream_id};
+    const size_t lds = att_bwd_lds(S);
+    static bool done16[64] = {}, done32[64] = {};
+    if (S <= 256) {
+        if (int rc = set_lds_attr(attention_bwd_kernel<16>, lds, done16)) return rc;
+        hipLaunchKernelGGL(attention_bwd_kernel<16>, dim3(B * h), dim3(kAttThreads), lds, (hipStream_t)stream, a);
+    } else {
+        if (int rc = set_lds_attr(attention_bwd_kernel<32>, lds, done32)) return rc;
+        hipLaunchKernelGGL(attention_bwd_kernel<32>, dim3(B * h), dim3(kAttThreads), lds, (hipStream_t)stream, a);
+    }
+    return status();
+}
+
+int ltr_enc_score_fwd(const float *x, const float *a, const float *b, const float *w, const float *bias, int64_t T, int d,
+                      float eps, int norm, float *scores, void *stream) {
+    if (!x || !w || !bias || !scores || (norm && (!a || !b))) return LTR_ERR_NULL;
+    if (T < 0 || d < 2 || d > 64 * kLnMax) return LTR_ERR_SHAPE;
+    if (norm < 0 || norm > 2) return LTR_ERR_PARAM;
+    if (T == 0) return LTR_OK;
+    hipLaunchKernelGGL(score_fwd_kernel, dim3(elt_grid(T, 4)), dim3(kLnThreads), 0, (hipStream_t)stream, x, a, b, w, bias, (long long)T,
+                       d, eps, norm, scores);
+    return status();
+}
+
+int ltr_enc_score_bwd(const float *x, const float *a, const float *b, const float *w, const float *dscores, int64_t T, int d,
+                      float eps, int norm, float *dx, float *partials, int nblk, void *stream) {
+    if (!x || !w || !dscores || !dx || !partials || (norm && (!a || !b))) return LTR_ERR_NULL;
+    if (T < 0 || d < 2 || d > 64 * kLnMax || nblk < 1 || nblk > 65535) return LTR_ERR_SHAPE;
+    if (norm < 0 || norm > 2) return LTR_ERR_PARAM;
+    hipLaunchKernelGGL(score_bwd_kernel, dim3(nblk), dim3(kLnThreads), 0, (hipStream_t)stream, x, a, b, w, dscores, (long long)T, d, eps,
+                       norm, dx, partials);
+    return status();
+}
+
+}  // extern "C"

@@ -1,7 +1,7 @@
 """ctypes binding of libltr_mi355x.so (the C ABI declared in include/ltr_mi355x.h)."""
 import ctypes
 import os
-from ctypes import c_char_p, c_float, c_int, c_int64, c_void_p
+from ctypes import c_char_p, c_float, c_int, c_int64, c_uint64, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # LTR_LIB: alternative build of the same ABI (kernel A/B experiments); default is the in-tree library.
@@ -42,6 +42,20 @@ _PROTOTYPES = {
     "ltr_svmlight_scan": (c_int, [c_char_p, P, P, P, c_int]),
     "ltr_svmlight_load": (c_int, [c_char_p, c_int64, c_int, c_int, P, P, P, c_int]),
     "ltr_gather_rows_f32": (c_int, [P, c_int64, P, c_int64, c_int64, P, P]),
+    # include/ltr_encoder.h (row f-3)
+    "ltr_enc_cast_bf16": (c_int, [P, P, c_int64, P]),
+    "ltr_enc_dropout_mask": (c_int, [c_uint64, c_int, c_int64, c_float, P, P]),
+    "ltr_enc_attn_dropout_mask": (c_int, [c_uint64, c_int, c_int, c_int, c_int, c_float, P, P]),
+    "ltr_enc_sum_partials": (c_int, [P, c_int, c_int64, c_int, P, P]),
+    "ltr_enc_layernorm_fwd": (c_int, [P, P, P, c_int64, c_int, c_float, c_int, P, P, P]),
+    "ltr_enc_layernorm_bwd": (c_int, [P, P, P, c_int64, c_int, c_float, c_int, P, P, c_int, P]),
+    "ltr_enc_gemm_bf16": (c_int, [P, P]),
+    "ltr_enc_colsum_bf16": (c_int, [P, c_int64, c_int, P, c_int, P]),
+    "ltr_enc_drop_cast_colsum": (c_int, [P, c_int64, c_int, c_float, c_uint64, c_int, P, P, c_int, P]),
+    "ltr_enc_attention_fwd": (c_int, [P, P, c_int, c_int, c_int, c_int, c_float, c_uint64, c_int, P, P]),
+    "ltr_enc_attention_bwd": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_float, c_uint64, c_int, P, P]),
+    "ltr_enc_score_fwd": (c_int, [P, P, P, P, P, c_int64, c_int, c_float, c_int, P, P]),
+    "ltr_enc_score_bwd": (c_int, [P, P, P, P, P, c_int64, c_int, c_float, c_int, P, P, c_int, P]),
     "ltr_ordinal_num_blocks": (c_int64, [c_int64]),
     "ltr_ordinal_fwd_bwd": (c_int, [P, P, c_int64, c_int, c_float, P, P, P, P]),
 }

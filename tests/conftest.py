@@ -48,9 +48,10 @@ def golden(group):
 
 
 def _manifest():
-    """manifest.json (round 1: approx / listnet / lambda / ordinal / scorers) + manifest_r2.json (risk / metrics)."""
+    """manifest.json (round 1: approx / listnet / lambda / ordinal / scorers) + manifest_r2.json (risk / metrics) +
+    manifest_r3.json (encoder)."""
     out = {}
-    for name in ("manifest.json", "manifest_r2.json"):
+    for name in ("manifest.json", "manifest_r2.json", "manifest_r3.json"):
         with open(os.path.join(GOLDEN, name)) as f:
             out.update({k: v for k, v in json.load(f).items() if not k.startswith("_")})
     return out

@@ -1,0 +1,399 @@
+"""GPU parity of the set-transformer scorer (BASELINE config 5): csrc/ltr_encoder.hip through the C ABI.
+
+Tolerances (stated here, used below):
+  * kernels in isolation, on bf16-representable inputs, vs torch fp64 on the SAME inputs:
+        GEMM / column sums / LayerNorm / scoring tail: 2e-5 (fp32 accumulation order only; bf16 outputs: 2^-8 rounding)
+        attention: 1e-2 of the tensor's max (P, dS and the outputs are rounded to bf16 inside the kernel)
+  * whole network vs the reference's golden vectors (fp32 CPU, tests/golden/encoder.npz): scores / loss 3e-2; parameter
+    gradients: cosine of the whole gradient > 0.99 and every tensor within 0.35 of its scale (bf16 rounding flips ReLU
+    units whose pre-activation is near zero -- O(1) for that unit in these tiny nets) -- the bf16-operand arithmetic
+    BASELINE config 5 asks for, NOT the 1e-5 bar of the fp32 rows;
+  * whole network vs the oracle with the same rounding points in its forward (bf16=True, fp64 otherwise): scores 1e-2,
+    every parameter gradient within 8e-2 (max-norm) and 3e-2 (L2) of max(its own scale, 5 % of the case's largest
+    gradient entry) -- the fp64 oracle and the fp32-accumulating kernels still disagree on a few near-zero ReLU inputs."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import golden, ledger_record, relerr
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module")
+def enc():
+    from ltr_mi355x import encoder
+    return encoder
+
+
+def bits(t):
+    """fp32/fp64 tensor -> int16 tensor of bf16 bit patterns (values must already be what we want rounded)."""
+    return t.to(torch.bfloat16).view(torch.int16)
+
+
+def unbits(t):
+    return t.view(torch.bfloat16).double()
+
+
+def rnd(*shape, scale=1.0):
+    """bf16-representable random values as fp64."""
+    return (torch.randn(*shape, device=DEV) * scale).to(torch.bfloat16).double()
+
+
+def err(a, b, floor=1e-30):
+    a, b = a.double(), b.double()
+    return float((a - b).abs().max()) / max(float(b.abs().max()), floor)
+
+
+# ------------------------------------------------------------------------------------------------- GEMM
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (200, 136, 136), (1000, 384, 128), (77, 8, 8), (256, 2048, 128), (300, 128, 2048)])
+def test_gemm_forward_form(enc, M, N, K):
+    torch.manual_seed(M + N + K)
+    A, W, bias = rnd(M, K), rnd(N, K, scale=0.2), torch.randn(N, device=DEV)
+    Cf = torch.empty(M, N, device=DEV)
+    Cb = torch.empty(M, N, dtype=torch.int16, device=DEV)
+    enc.gemm(bits(A), bits(W), M, N, K, Cf=Cf, Cb=Cb, bias=bias)
+    want = A @ W.t() + bias.double()
+    assert err(Cf, want) < 2e-5
+    assert err(unbits(Cb), want) < 5e-3
+
+
+def test_gemm_epilogue_relu_dropout_residual_gate(enc):
+    torch.manual_seed(7)
+    M, N, K, p, seed, sid = 333, 264, 72, 0.25, 1234567, 5
+    A, W, bias, res = rnd(M, K), rnd(N, K, scale=0.3), torch.randn(N, device=DEV), torch.randn(M, N, device=DEV)
+    keep = enc.dropout_mask(seed, sid, M * N, p, DEV).view(M, N).double()
+    assert abs(float(keep.mean()) - (1 - p)) < 0.01
+    Cf = torch.empty(M, N, device=DEV)
+    enc.gemm(bits(A), bits(W), M, N, K, Cf=Cf, bias=bias, relu=True, drop_p=p, seed=seed, drop_stream=sid, residual=res)
+    want = torch.relu(A @ W.t() + bias.double()) * keep / (1 - p) + res.double()
+    assert err(Cf, want) < 2e-5
+    gate = rnd(M, N)
+    Cb = torch.empty(M, N, dtype=torch.int16, device=DEV)
+    enc.gemm(bits(A), bits(W), M, N, K, Cb=Cb, gate=bits(gate), gate_scale=1.0 / (1 - p))
+    want = (A @ W.t()) * (gate > 0).double() / (1 - p)
+    assert err(unbits(Cb), want) < 5e-3
+
+
+@pytest.mark.parametrize("T,N,K", [(512, 128, 136), (1000, 136, 2048), (77, 264, 8)])
+def test_gemm_input_gradient_form(enc, T, N, K):
+    """dx = dy W: A = dy [T][N] k-contiguous, B = W [N][K] read k-major."""
+    torch.manual_seed(T)
+    dy, W = rnd(T, N), rnd(N, K, scale=0.2)
+    Cf = torch.empty(T, K, device=DEV)
+    enc.gemm(bits(dy), bits(W), T, K, N, b_kmajor=True, Cf=Cf)
+    assert err(Cf, dy @ W) < 2e-5
+
+
+@pytest.mark.parametrize("T,N,K,splits", [(512, 128, 136, 1), (5000, 2048, 128, 7), (1003, 136, 408, 3), (40, 8, 16, 4)])
+def test_gemm_weight_gradient_form_split_k(enc, T, N, K, splits):
+    """dW = dy^T x: both operands k-major, split over the tokens + fixed-order reduce."""
+    torch.manual_seed(T)
+    dy, x = rnd(T, N), rnd(T, K)
+    parts = torch.empty(splits, N, K, device=DEV)
+    enc.gemm(bits(dy), bits(x), N, K, T, a_kmajor=True, b_kmajor=True, Cf=parts, splits=splits)
+    got = enc.sum_partials(parts, splits, N * K).view(N, K) if splits > 1 else parts[0]
+    assert err(got, dy.t() @ x) < 2e-5
+    assert err(enc._weight_grad(bits(dy), bits(x), T, N, K), dy.t() @ x) < 2e-5
+
+
+def test_gemm_rejects_bad_shapes(enc):
+    from ltr_mi355x._lib import LtrError
+    a = torch.zeros(16, 12, dtype=torch.int16, device=DEV)
+    with pytest.raises(LtrError):
+        enc.gemm(a, a, 16, 16, 12, Cf=torch.empty(16, 16, device=DEV))      # K % 8 != 0
+
+
+# ------------------------------------------------------------------------------------------------- reductions
+def test_colsum_and_drop_cast_colsum(enc):
+    torch.manual_seed(3)
+    for T, N in ((1000, 128), (37, 2048), (5, 8), (4097, 136)):
+        y = rnd(T, N)
+        assert err(enc._colsum(bits(y), T, N), y.sum(0)) < 2e-5
+        dx = torch.randn(T, N, device=DEV)
+        p, seed, sid = 0.1, 99, 3
+        out, cs = enc._drop_cast_colsum(dx, T, N, p, seed, sid)
+        keep = enc.dropout_mask(seed, sid, T * N, p, DEV).view(T, N)
+        want = (dx * keep / (1 - p)).to(torch.bfloat16)
+        assert torch.equal(out.view(torch.bfloat16), want)
+        assert err(cs, want.double().sum(0)) < 2e-5
+        out0, _ = enc._drop_cast_colsum(dx, T, N, 0.0, seed, sid)
+        assert torch.equal(out0.view(torch.bfloat16), dx.to(torch.bfloat16))
+
+
+# ------------------------------------------------------------------------------------------------- LayerNorm / scoring tail
+def _ln_ref(x, a, b, eps, standard):
+    if standard:
+        return torch.nn.functional.layer_norm(x, (x.shape[-1],), a, b, eps)
+    return a * (x - x.mean(-1, keepdim=True)) / (x.std(-1, keepdim=True) + eps) + b
+
+
+@pytest.mark.parametrize("d", [16, 128, 136, 264, 512])
+@pytest.mark.parametrize("standard", [0, 1])
+def test_layernorm_fwd_bwd(enc, d, standard):
+    torch.manual_seed(d)
+    T, eps = 301, 1e-5 if standard else 1e-6
+    x = torch.randn(T, d, device=DEV) * 2 + 0.5
+    a, b = torch.randn(d, device=DEV), torch.randn(d, device=DEV)
+    yb, yf = enc.layernorm_fwd(x, a, b, T, d, eps, standard, want_f32=True)
+    xr, ar, br = (t.double().requires_grad_(True) for t in (x, a, b))
+    want = _ln_ref(xr, ar, br, eps, standard)
+    assert err(yf, want) < 2e-5
+    assert err(unbits(yb), want) < 5e-3
+    dy = torch.randn(T, d, device=DEV)
+    want.backward(dy.double())
+    dx0 = torch.randn(T, d, device=DEV)
+    dx = dx0.clone()
+    ga, gb = enc.layernorm_bwd(x, a, dy, T, d, eps, standard, dx)
+    assert err(dx - dx0, xr.grad) < 5e-5
+    assert err(ga, ar.grad) < 2e-5 and err(gb, br.grad) < 2e-5
+
+
+@pytest.mark.parametrize("norm", [0, 1])
+def test_score_tail_fwd_bwd(enc, norm):
+    from ltr_mi355x._lib import check, lib
+    from ltr_mi355x.functional import _ptr, _stream
+    torch.manual_seed(11)
+    T, d = 515, 136
+    x = torch.randn(T, d, device=DEV)
+    a, b, w, bias = (torch.randn(n, device=DEV) for n in (d, d, d, 1))
+    s = torch.empty(T, device=DEV)
+    check(lib().ltr_enc_score_fwd(_ptr(x), _ptr(a), _ptr(b), _ptr(w), _ptr(bias), T, d, 1e-6, norm, _ptr(s), _stream()), "f")
+    xr, ar, br, wr, cr = (t.double().requires_grad_(True) for t in (x, a, b, w, bias))
+    y = _ln_ref(xr, ar, br, 1e-6, 0) if norm else xr
+    want = y @ wr + cr
+    assert err(s, want) < 2e-5
+    ds = torch.randn(T, device=DEV)
+    want.backward(ds.double())
+    nblk = 64
+    dx = torch.empty(T, d, device=DEV)
+    parts = torch.empty(nblk, 3 * d + 8, device=DEV)
+    check(lib().ltr_enc_score_bwd(_ptr(x), _ptr(a), _ptr(b), _ptr(w), _ptr(ds), T, d, 1e-6, norm, _ptr(dx), _ptr(parts), nblk,
+                                  _stream()), "b")
+    g = enc.sum_partials(parts, nblk, 3 * d + 8)
+    assert err(dx, xr.grad) < 5e-5
+    assert err(g[2 * d:3 * d], wr.grad) < 2e-5 and err(g[3 * d:3 * d + 1], cr.grad) < 2e-5
+    if norm:
+        assert err(g[:d], ar.grad) < 2e-5 and err(g[d:2 * d], br.grad) < 2e-5
+
+
+# ------------------------------------------------------------------------------------------------- attention
+def _attention_ref(q, k, v, pad, keep, p, dk):
+    """transformer.py:145-164 on [B, h, S, dk] fp64 tensors; P rounded to bf16 after dropout like the kernel."""
+    sc = q @ k.transpose(-2, -1) / math.sqrt(dk)
+    sc = sc.masked_fill(pad, float("-inf"))
+    pa = torch.softmax(sc, dim=-1)
+    if keep is not None:
+        pa = pa * keep / (1 - p)
+    return pa @ v
+
+
+@pytest.mark.parametrize("B,S,h,dk,p", [(2, 12, 4, 8, 0.0), (3, 33, 8, 17, 0.1), (2, 100, 8, 16, 0.1), (1, 256, 4, 32, 0.0),
+                                        (2, 256, 8, 16, 0.2), (1, 300, 2, 24, 0.1), (1, 512, 1, 32, 0.0)])
+def test_attention_fwd_bwd(enc, B, S, h, dk, p):
+    from ltr_mi355x._lib import check, lib
+    from ltr_mi355x.functional import _ptr, _stream
+    torch.manual_seed(S * h + dk)
+    d, T, seed, sid = h * dk, B * S, 4242, 16
+    qkv = rnd(T, 3 * d, scale=1.5)
+    mask = torch.zeros(B, S, dtype=torch.uint8, device=DEV)
+    mask[0, S - S // 4:] = 1
+    ctx = torch.empty(T, d, dtype=torch.int16, device=DEV)
+    check(lib().ltr_enc_attention_fwd(_ptr(bits(qkv)), _ptr(mask), B, S, h, dk, p, seed, sid, _ptr(ctx), _stream()), "fwd")
+    keep = enc.attn_dropout_mask(seed, sid, B, S, h, p, DEV).double() if p else None
+    if p:
+        assert abs(float(keep.mean()) - (1 - p)) < 0.02
+    qr = qkv.clone().requires_grad_(True)
+    q, k, v = (qr[:, j * d:(j + 1) * d].view(B, S, h, dk).transpose(1, 2) for j in range(3))
+    want = _attention_ref(q, k, v, (mask == 1).view(B, 1, 1, S), keep, p, dk).transpose(1, 2).reshape(T, d)
+    assert err(unbits(ctx), want) < 1e-2
+    dctx = rnd(T, d)
+    want.backward(dctx)
+    dqkv = torch.empty(T, 3 * d, dtype=torch.int16, device=DEV)
+    check(lib().ltr_enc_attention_bwd(_ptr(bits(qkv)), _ptr(bits(dctx)), _ptr(mask), B, S, h, dk, p, seed, sid, _ptr(dqkv),
+                                      _stream()), "bwd")
+    got = unbits(dqkv)
+    for j, name in enumerate("qkv"):
+        e = err(got[:, j * d:(j + 1) * d], qr.grad[:, j * d:(j + 1) * d])
+        assert e < 1.5e-2, f"d{name}: {e}"
+
+
+def test_attention_without_mask_and_all_masked_slate(enc):
+    from ltr_mi355x._lib import check, lib
+    from ltr_mi355x.functional import _ptr, _stream
+    B, S, h, dk = 2, 40, 2, 16
+    d, T = h * dk, B * S
+    qkv = rnd(T, 3 * d)
+    ctx = torch.empty(T, d, dtype=torch.int16, device=DEV)
+    check(lib().ltr_enc_attention_fwd(_ptr(bits(qkv)), None, B, S, h, dk, 0.0, 0, 0, _ptr(ctx), _stream()), "fwd")
+    q, k, v = (qkv[:, j * d:(j + 1) * d].view(B, S, h, dk).transpose(1, 2) for j in range(3))
+    want = _attention_ref(q, k, v, torch.zeros(B, 1, 1, S, dtype=torch.bool, device=DEV), None, 0.0, dk).transpose(1, 2).reshape(T, d)
+    assert err(unbits(ctx), want) < 1e-2
+    mask = torch.zeros(B, S, dtype=torch.uint8, device=DEV)
+    mask[1] = 1                                  # the reference yields NaN for this slate; the kernel yields zeros (header)
+    check(lib().ltr_enc_attention_fwd(_ptr(bits(qkv)), _ptr(mask), B, S, h, dk, 0.0, 0, 0, _ptr(ctx), _stream()), "fwd")
+    got = unbits(ctx).view(B, S, d)
+    assert err(got[0], want.view(B, S, d)[0]) < 1e-2 and float(got[1].abs().max()) == 0.0
+
+
+# ------------------------------------------------------------------------------------------------- whole network
+def _build(case, g):
+    from architeture.multiLayer import make_model
+    import copy
+    net = make_model(fc_model=copy.deepcopy(case["fc_model"]), transformer=copy.deepcopy(case["transformer"]),
+                     post_model=dict(d_output=1, output_activation="Sigmoid"), n_features=case["n_features"])
+    sd = {k: torch.from_numpy(g.arr(case, "w/" + k)) for k in case["keys"]}
+    assert list(net.state_dict().keys()) == case["keys"]
+    net.load_state_dict(sd)
+    return net.to(DEV), sd
+
+
+@pytest.mark.parametrize("case", golden("encoder").cases, ids=lambda c: c["id"])
+def test_network_vs_reference_golden(case):
+    import ltr_encoder_oracle as EO
+    import ltr_oracle as O
+    from losses.approxNDCG import approxNDCGLoss
+    g = golden("encoder")
+    net, sd = _build(case, g)
+    net.eval()
+    x = torch.from_numpy(g.arr(case, "x")).to(DEV)
+    y = torch.from_numpy(g.arr(case, "y")).to(DEV)
+    mask = torch.from_numpy(g.arr(case, "mask")).to(DEV) if case["has_mask"] else None
+    scores = net(x, mask, None)
+    assert scores.shape == (case["B"], case["S"])
+    loss = approxNDCGLoss(scores, y)
+    loss.backward()
+    want_s = g.arr(case, "scores")
+    assert relerr(scores.detach().cpu().numpy(), want_s) < 3e-2
+    assert abs(float(loss) - float(g.arr(case, "loss"))) < 3e-2 * abs(float(g.arr(case, "loss")))
+    got = {k: p.grad.cpu().double() for k, p in net.named_parameters()}
+    # (1) vs the reference's fp32 gradients: bf16 rounding flips the sign of a few ReLU pre-activations near zero, which
+    # moves single FFN units' gradients by O(1) in these small nets -- so: direction of the whole gradient + a loose
+    # per-tensor bound here, and the tight per-tensor bound against the oracle that rounds where the kernels round (2)
+    ref = {k: torch.from_numpy(g.arr(case, "g/" + k)).double() for k in case["keys"]}
+    gmax = max(float(v.abs().max()) for v in ref.values())
+    flat_got, flat_ref = torch.cat([got[k].flatten() for k in ref]), torch.cat([ref[k].flatten() for k in ref])
+    cos = float(flat_got @ flat_ref / (flat_got.norm() * flat_ref.norm()))
+    assert cos > 0.99, cos
+    loose = {k: _gerr(got[k], ref[k], gmax) for k in ref}
+    assert max(loose.values()) < 0.35, {k: v for k, v in loose.items() if v >= 0.35}
+    # (2) same rounding points in the oracle's forward (straight-through in its fp64 backward)
+    cfg = EO.config_of(dict(fc_model=case["fc_model"], transformer=case["transformer"]), case["n_features"])
+    yc = torch.from_numpy(g.arr(case, "y")).double()
+    s_o, l_o, g_o = EO.scores_and_grads(sd, torch.from_numpy(g.arr(case, "x")), None if mask is None else mask.cpu(), cfg,
+                                        lambda s: O.approx_ndcg(s, yc), bf16=True)
+    assert relerr(scores.detach().cpu().numpy(), s_o.numpy()) < 1e-2
+    gmax = max(float(v.abs().max()) for v in g_o.values())
+    tight = {k: _gerr(got[k], g_o[k], gmax) for k in g_o}
+    assert max(tight.values()) < 8e-2, {k: v for k, v in tight.items() if v >= 8e-2}
+    l2 = {k: _l2err(got[k], g_o[k], gmax) for k in g_o}
+    assert max(l2.values()) < 3e-2, {k: v for k, v in l2.items() if v >= 3e-2}
+    note = "bf16-operand network (BASELINE config 5): bar is the bf16 one stated in this file, not 1e-5"
+    ledger_record("encoder scores vs reference fp32", relerr(scores.detach().cpu().numpy(), want_s), tol=3e-2, note=note)
+    ledger_record("encoder worst param-grad vs reference fp32", max(loose.values()), tol=0.35, note=note + f"; cosine {cos:.5f}")
+    ledger_record("encoder worst param-grad vs bf16-rounding oracle (max-norm)", max(tight.values()), tol=8e-2, note=note)
+    ledger_record("encoder worst param-grad vs bf16-rounding oracle (L2)", max(l2.values()), tol=3e-2, note=note)
+
+
+def _l2err(a, b, gmax):
+    """|a-b|_2 / |b|_2 with the same 5 % floor per entry."""
+    return float((a - b).norm()) / max(float(b.norm()), 0.05 * gmax * math.sqrt(b.numel()))
+
+
+def _gerr(a, b, gmax):
+    """max|a-b| over max(|b|max, 5 % of the case's largest gradient entry)."""
+    return float((a - b).abs().max()) / max(float(b.abs().max()), 0.05 * gmax)
+
+
+def test_network_train_mode_dropout_matches_oracle_under_exported_masks(enc):
+    import ltr_encoder_oracle as EO
+    from architeture.multiLayer import make_model
+    from losses.approxNDCG import approxNDCGLoss
+    torch.manual_seed(5)
+    F, B, S = 24, 3, 40
+    fc = dict(sizes=[48, 32], input_norm=False, activation=None, dropout=0.2)
+    tr = dict(N=2, d_ff=64, h=4, dropout=0.1, positional_encoding=None)
+    import copy
+    net = make_model(copy.deepcopy(fc), copy.deepcopy(tr), dict(d_output=1, output_activation=None), F).to(DEV)
+    net.train()
+    x = torch.randn(B, S, F, device=DEV)
+    y = torch.randint(0, 5, (B, S), device=DEV).float()
+    mask = torch.zeros(B, S, dtype=torch.bool, device=DEV)
+    mask[1, 30:] = True
+    y[mask] = -1
+    net.ltr_seed = 77
+    scores = net(x, mask, None)
+    seed = (77 + 0x9E3779B97F4A7C15) & (2 ** 64 - 1)
+    approxNDCGLoss(scores, y).backward()
+    T, d, dff, h = B * S, 32, 64, 4
+    keep = {("fc", 0): enc.dropout_mask(seed, enc.stream_fc(0), T * 48, 0.2, DEV).view(T, 48).cpu(),
+            ("fc", 1): enc.dropout_mask(seed, enc.stream_fc(1), T * 32, 0.2, DEV).view(T, 32).cpu()}
+    for l in range(2):
+        keep[("attn", l)] = enc.attn_dropout_mask(seed, enc.stream_attn(l), B, S, h, 0.1, DEV).cpu()
+        keep[("attn_out", l)] = enc.dropout_mask(seed, enc.stream_attn_out(l), T * d, 0.1, DEV).view(T, d).cpu()
+        keep[("ffn_hidden", l)] = enc.dropout_mask(seed, enc.stream_ffn_hidden(l), T * dff, 0.1, DEV).view(T, dff).cpu()
+        keep[("ffn_out", l)] = enc.dropout_mask(seed, enc.stream_ffn_out(l), T * d, 0.1, DEV).view(T, d).cpu()
+    sd = {k: v.detach().cpu() for k, v in net.state_dict().items()}
+    cfg = EO.config_of(dict(fc_model=fc, transformer=tr), F)
+    import ltr_oracle as O
+    yc = y.cpu().double()
+    s_o, _, g_o = EO.scores_and_grads(sd, x.cpu(), mask.cpu(), cfg, lambda s: O.approx_ndcg(s, yc), keep=keep, bf16=True)
+    assert relerr(scores.detach().cpu().numpy(), s_o.numpy()) < 1e-2
+    gmax = max(float(v.abs().max()) for v in g_o.values())
+    worst = {k: _gerr(p.grad.cpu().double(), g_o[k], gmax) for k, p in net.named_parameters()}
+    assert max(worst.values()) < 8e-2, {k: v for k, v in worst.items() if v >= 8e-2}
+    l2 = {k: _l2err(p.grad.cpu().double(), g_o[k], gmax) for k, p in net.named_parameters()}
+    assert max(l2.values()) < 3e-2, {k: v for k, v in l2.items() if v >= 3e-2}
+    # a second training forward draws new masks; eval mode is deterministic and mask-free
+    s2 = net(x, mask, None)
+    assert not torch.equal(s2, scores)
+    net.eval()
+    assert torch.equal(net(x, mask, None), net(x, mask, None))
+
+
+def test_network_api_errors_and_features(enc):
+    from architeture.multiLayer import make_model
+    from ltr_mi355x._lib import LtrDeviceError
+    tr = dict(N=1, d_ff=32, h=2, dropout=0.0, positional_encoding=None)
+    net = make_model(None, tr, dict(d_output=1), 16).to(DEV).eval()
+    x = torch.randn(2, 10, 16, device=DEV)
+    with pytest.raises(AttributeError):
+        net(x, None, None)                      # transformer.py:55 dereferences the mask
+    with pytest.raises(LtrDeviceError):
+        net.cpu()(x.cpu(), torch.zeros(2, 10), None)
+    net.to(DEV)
+    mask = torch.zeros(2, 10, dtype=torch.bool, device=DEV)
+    feats = net.prepare_for_output(x, mask, None)
+    assert feats.shape == (2, 10, 16)
+    w, b = net.output_layer.w_1.weight.detach(), net.output_layer.w_1.bias.detach()
+    assert relerr((feats @ w.t() + b).squeeze(2).cpu().numpy(), net.score(x, mask, None).detach().cpu().numpy()) < 1e-5
+    fc_only = make_model(dict(sizes=[32, 8], input_norm=False, activation=None, dropout=0.0), None, dict(d_output=1), 16).to(DEV)
+    s = fc_only(x, None, None)                  # no encoder: mask may be None (main_batch_execution.py:124)
+    assert s.shape == (2, 10)
+    with pytest.raises(ValueError):
+        make_model(dict(sizes=[30], input_norm=False, activation=None, dropout=0.0), None, dict(d_output=1), 16).to(DEV)(x, None, None)
+
+
+def test_network_trains(enc):
+    """A few Adam steps on a fixed batch reduce the approxNDCG loss (the whole fwd/bwd chain has the right sign)."""
+    from architeture.multiLayer import make_model
+    from losses.approxNDCG import approxNDCGLoss
+    torch.manual_seed(1)
+    net = make_model(dict(sizes=[64], input_norm=False, activation=None, dropout=0.0),
+                     dict(N=2, d_ff=128, h=4, dropout=0.0, positional_encoding=None), dict(d_output=1), 136).to(DEV)
+    x = torch.randn(16, 64, 136, device=DEV)
+    y = torch.randint(0, 5, (16, 64), device=DEV).float()
+    mask = torch.zeros(16, 64, dtype=torch.bool, device=DEV)
+    opt = torch.optim.Adam(net.parameters(), lr=1e-3)
+    losses = []
+    for _ in range(30):
+        opt.zero_grad()
+        loss = approxNDCGLoss(net(x, mask, None), y)
+        loss.backward()
+        opt.step()
+        losses.append(float(loss))
+    assert losses[-1] < losses[0] - 0.05, losses
