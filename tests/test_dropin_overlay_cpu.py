@@ -13,7 +13,8 @@ from conftest import PKG
 
 STUB = {
     "architeture/__init__.py": "",
-    "architeture/multiLayer.py": "def make_model(*a, **k):\n    return 'stub-make_model'\n",
+    "architeture/multiLayer.py": "STUB = True\ndef make_model(*a, **k):\n    return 'stub-make_model'\n",     # shadowed (row f-3)
+    "architeture/customNet.py": "def make_custom(*a, **k):\n    return 'stub-make_custom'\n",               # falls through
     "architeture/doubleLayer.py": "class DoubleLayerNet:\n    STUB = True\n",          # must be shadowed
     "config.py": "class Config:\n    pass\n",
     "losses/__init__.py": "from losses import approxNDCG\nfrom losses import exactNDCG\nfrom losses import lambdaL\n"
@@ -44,21 +45,25 @@ CHILD = textwrap.dedent("""
     from losses.riskLosses.riskFunctions import geoRisk
     from utils.dataset import get_data, svmDataset, get_baseline_data
     from utils.metrics import mNdcg
+    from architeture.customNet import make_custom
     import losses, architeture, losses.extraExperiment, utils.computeMetrics, utils.metrics, utils.dataset
+    import architeture.multiLayer, architeture.transformer
     pkg, stub = sys.argv[1], sys.argv[2]
     inside = lambda m, d: os.path.abspath(sys.modules[m].__file__).startswith(os.path.abspath(d) + os.sep)
     for m in ("losses", "losses.approxNDCG", "losses.lambdaL", "losses.listnet", "architeture",
-              "architeture.doubleLayer", "architeture.tripleLayer", "utils.metrics", "utils.dataset"):
+              "architeture.doubleLayer", "architeture.tripleLayer", "architeture.multiLayer", "architeture.transformer",
+              "utils.metrics", "utils.dataset"):
         assert inside(m, pkg), (m, sys.modules[m].__file__)
     # the risk losses (SURVEY.md row f-1) resolve here once this package provides them, else in the caller's tree
     ours = os.path.exists(os.path.join(pkg, "losses", "riskLosses", "riskLosses.py"))
     for m in ("losses.riskLosses.riskLosses", "losses.riskLosses.riskFunctions"):
         assert inside(m, pkg if ours else stub), (m, sys.modules[m].__file__)
         assert hasattr(sys.modules[m], "STUB") != ours
-    for m in ("architeture.multiLayer", "losses.exactNDCG", "losses.orderScore", "losses.extraExperiment", "config",
+    for m in ("architeture.customNet", "losses.exactNDCG", "losses.orderScore", "losses.extraExperiment", "config",
               "utils.computeMetrics"):
         assert inside(m, stub), (m, sys.modules[m].__file__)
-    assert make_model() == "stub-make_model" and losses.extraExperiment.VALUE == 41 and utils.computeMetrics.VALUE == 7
+    assert not hasattr(architeture.multiLayer, "STUB") and make_custom() == "stub-make_custom"
+    assert losses.extraExperiment.VALUE == 41 and utils.computeMetrics.VALUE == 7
     assert not hasattr(utils.metrics, "STUB") and not hasattr(utils.dataset, "STUB")
     assert not hasattr(DoubleLayerNet, "STUB") and not hasattr(losses.approxNDCG, "STUB")
     # `from losses import *` binds what the reference's losses/__init__.py binds (:1-5)
