@@ -85,9 +85,10 @@ int ltr_enc_drop_cast_colsum(const float *dx, int64_t T, int N, float p, uint64_
  *   masked yields zeros (the reference yields NaN). */
 int ltr_enc_attention_fwd(const uint16_t *qkv, const uint8_t *mask, int B, int S, int h, int dk, float drop_p,
                           uint64_t seed, int stream_id, uint16_t *ctx, void *stream);
-/* dqkv [T][3*d] bf16 from dctx [T][d] bf16; probabilities are recomputed. */
-int ltr_enc_attention_bwd(const uint16_t *qkv, const uint16_t *dctx, const uint8_t *mask, int B, int S, int h, int dk,
-                          float drop_p, uint64_t seed, int stream_id, uint16_t *dqkv, void *stream);
+/* dqkv [T][3*d] bf16 from dctx [T][d] bf16 and the forward's output ctx [T][d] (row sums dP . P = dctx . ctx per head);
+ * probabilities are recomputed. */
+int ltr_enc_attention_bwd(const uint16_t *qkv, const uint16_t *ctx, const uint16_t *dctx, const uint8_t *mask, int B, int S, int h,
+                          int dk, float drop_p, uint64_t seed, int stream_id, uint16_t *dqkv, void *stream);
 
 /* ---- Encoder.norm + OutputLayer.w_1 with d_output = 1 (transformer.py:59, multiLayer.py:104-113):
  *   scores[t] = w . LN(x[t]) + bias     (norm: 0 = none, 1 = transformer.py LayerNorm, 2 = nn.LayerNorm)

@@ -49,11 +49,14 @@ __device__ __forceinline__ unsigned mix32(unsigned h) {
     h ^= h >> 16; h *= 0x85EBCA6Bu; h ^= h >> 13; h *= 0xC2B2AE35u; h ^= h >> 16;
     return h;
 }
-// 32 hash bits shared by elements 2*pair and 2*pair + 1 of stream `stream_id`
+// 32 hash bits shared by elements 2*pair and 2*pair + 1 of stream `stream_id`: one murmur3 finaliser over the pair
+// counter xor a per-(seed, stream) key.  The key is wave-uniform (hoisted out of every loop by the compiler); per
+// element pair this costs two 32-bit multiplies.
+__device__ __forceinline__ unsigned drop_key(unsigned long long seed, int stream_id) {
+    return mix32((unsigned)seed ^ (0x9E3779B9u * (unsigned)(stream_id + 1))) ^ mix32((unsigned)(seed >> 32) + 0x85EBCA6Bu * (unsigned)stream_id);
+}
 __device__ __forceinline__ unsigned drop_word(unsigned long long seed, int stream_id, unsigned long long pair) {
-    unsigned h = (unsigned)seed ^ (0x9E3779B9u * (unsigned)(stream_id + 1));
-    h = mix32(h ^ (unsigned)pair);
-    return mix32(h ^ (unsigned)(pair >> 32) ^ (unsigned)(seed >> 32));
+    return mix32((unsigned)pair ^ drop_key(seed, stream_id) ^ (0x27D4EB2Fu * (unsigned)(pair >> 32)));
 }
 __host__ __device__ inline unsigned drop_threshold(float p) {
     if (!(p > 0.f)) return 0u;
@@ -96,11 +99,39 @@ __global__ void cast_bf16_kernel(const float *__restrict__ src, bf16_t *__restri
         dst[e] = to_bf16(src[e]);
 }
 
-__global__ void sum_partials_kernel(const float *__restrict__ parts, int nsplit, long long n, int accumulate, float *__restrict__ out) {
-    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long long)gridDim.x * blockDim.x) {
-        double s = accumulate ? (double)out[e] : 0.0;
-        for (int z = 0; z < nsplit; ++z) s += (double)parts[(long long)z * n + e];
-        out[e] = (float)s;
+// out[e] = sum_z parts[z][e] in a fixed order: 256 threads = ZL z-lanes x EW outputs (EW = 256 / ZL consecutive e, so
+// loads stay coalesced); z-lane l sums z = l, l + ZL, ... in fp64, the ZL lane sums are then added in lane order.
+template <int ZL>
+__global__ void __launch_bounds__(256) sum_partials_kernel(const float *__restrict__ parts, int nsplit, long long n, int accumulate,
+                                                           float *__restrict__ out) {
+    constexpr int EW = 256 / ZL;
+    __shared__ double red[256];
+    const int el = threadIdx.x % EW, zl = threadIdx.x / EW;
+    for (long long e0 = (long long)blockIdx.x * EW; e0 < n; e0 += (long long)gridDim.x * EW) {
+        const long long e = e0 + el;
+        double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+        if (e < n) {
+            int z = zl;
+            for (; z + 3 * ZL < nsplit; z += 4 * ZL) {
+                s0 += (double)parts[(long long)z * n + e];
+                s1 += (double)parts[(long long)(z + ZL) * n + e];
+                s2 += (double)parts[(long long)(z + 2 * ZL) * n + e];
+                s3 += (double)parts[(long long)(z + 3 * ZL) * n + e];
+            }
+            for (; z < nsplit; z += ZL) s0 += (double)parts[(long long)z * n + e];
+        }
+        double s = (s0 + s1) + (s2 + s3);
+        if (ZL > 1) {
+            __syncthreads();
+            red[threadIdx.x] = s;
+            __syncthreads();
+            if (zl == 0) {
+                s = 0.0;
+#pragma unroll
+                for (int l = 0; l < ZL; ++l) s += red[l * EW + el];
+            }
+        }
+        if (zl == 0 && e < n) out[e] = (float)(accumulate ? (double)out[e] + s : s);
     }
 }
 
@@ -589,6 +620,7 @@ __host__ __device__ inline int tr_ld(int Sp) { return ((Sp / 2 + 59) / 64 * 64 +
 struct AttArgs {
     const bf16_t *qkv;
     const bf16_t *dctx;
+    const bf16_t *ctx;    // backward only: the forward's output
     const uint8_t *mask;
     bf16_t *out;          // fwd: ctx [T][d]; bwd: dqkv [T][3d]
     int B, S, h, dk;
@@ -664,18 +696,20 @@ __device__ __forceinline__ float quad_max(float v) {
     return fmaxf(v, __shfl_xor(v, 32, 64));
 }
 
-// Softmax probabilities of one 16-query tile in the S^T orientation: st[kt][r] = score of key 16 kt + 4 g + r for
-// query (lane & 15), in place -> p; returns row max / 1/sum through m, inv.
+// Softmax probabilities of one 16-query tile in the S^T orientation: st[kt][r] = raw score (q . k) of key
+// 16 kt + 4 g + r for query (lane & 15), in place -> p.  Base-2 arithmetic: c2 = log2(e) / sqrt(dk) is folded into the
+// exponent; lse2 = log2 sum_k 2^(c2 s_k) (+inf for a query without any unmasked key) lets the key-major backward
+// phase recompute p = 2^(c2 s - lse2) with one fma and one v_exp_f32.
 template <int KTMAX>
-__device__ __forceinline__ void softmax_tile(f32x4 (&st)[KTMAX], int KT, const uint8_t *maskS, float scale, int g, float &m, float &inv) {
-    m = -INFINITY;
+__device__ __forceinline__ void softmax_tile(f32x4 (&st)[KTMAX], int KT, const float *biasS, float c2, int g, float &lse2) {
+    float m = -INFINITY;
 #pragma unroll
     for (int kt = 0; kt < KTMAX; ++kt)
         if (kt < KT) {
-            const unsigned mk = *reinterpret_cast<const unsigned *>(maskS + 16 * kt + 4 * g);
+            const f32x4 bias = *reinterpret_cast<const f32x4 *>(biasS + 16 * kt + 4 * g);     // 0, or -inf for masked keys
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                st[kt][r] = (mk >> (8 * r)) & 0xffu ? -INFINITY : st[kt][r] * scale;
+                st[kt][r] = fmaf(st[kt][r], c2, bias[r]);
                 m = fmaxf(m, st[kt][r]);
             }
         }
@@ -687,31 +721,34 @@ __device__ __forceinline__ void softmax_tile(f32x4 (&st)[KTMAX], int KT, const u
         if (kt < KT) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                st[kt][r] = __expf(st[kt][r] - m);
+                st[kt][r] = __builtin_amdgcn_exp2f(st[kt][r] - m);
                 l += st[kt][r];
             }
         }
     l = quad_sum(l);
-    inv = l > 0.f ? 1.f / l : 0.f;
+    const float inv = l > 0.f ? 1.f / l : 0.f;
+    lse2 = l > 0.f ? m + __builtin_amdgcn_logf(l) : INFINITY;
 #pragma unroll
     for (int kt = 0; kt < KTMAX; ++kt)
         if (kt < KT) st[kt] *= inv;
 }
 
-template <int KTMAX>
+// FULL: the padded slate fills all KTMAX key tiles (the `kt < KT` guards fold away)
+template <int KTMAX, bool FULL>
 __global__ void __launch_bounds__(kAttThreads) attention_fwd_kernel(AttArgs a) {
     extern __shared__ __attribute__((aligned(16))) bf16_t smem[];
-    const int Sp = round_up(a.S, 32), KT = Sp / 16, ldt = tr_ld(Sp);
+    const int Sp = round_up(a.S, 32), KT = FULL ? KTMAX : Sp / 16, ldt = tr_ld(Sp);
     bf16_t *Kimg = smem, *VT = Kimg + Sp * kRowLd;
-    uint8_t *maskS = reinterpret_cast<uint8_t *>(VT + kDkPad * ldt);
+    float *biasS = reinterpret_cast<float *>(VT + kDkPad * ldt);
     const int b = blockIdx.x / a.h, hd = blockIdx.x % a.h, d = a.h * a.dk;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, j = lane & 15, g = lane >> 4;
     const bool vec = a.dk % 8 == 0;
     stage_head(a, b, hd, 1, Sp, Kimg, nullptr, 0);
     stage_head(a, b, hd, 2, Sp, nullptr, VT, ldt);
-    for (int k = threadIdx.x; k < Sp; k += kAttThreads) maskS[k] = k >= a.S || (a.mask && a.mask[(long long)b * a.S + k] == 1) ? 1 : 0;
+    for (int k = threadIdx.x; k < Sp; k += kAttThreads)
+        biasS[k] = k >= a.S || (a.mask && a.mask[(long long)b * a.S + k] == 1) ? -INFINITY : 0.f;
     __syncthreads();
-    const float scale = 1.f / sqrtf((float)a.dk);
+    const float c2 = 1.44269504088896341f / sqrtf((float)a.dk);
     const unsigned thr = drop_threshold(a.drop_p);
     const float ks = thr ? 1.f / (1.f - a.drop_p) : 1.f;
     for (int qt = w; qt * 16 < a.S; qt += kAttThreads / 64) {
@@ -720,9 +757,12 @@ __global__ void __launch_bounds__(kAttThreads) attention_fwd_kernel(AttArgs a) {
         f32x4 st[KTMAX];
 #pragma unroll
         for (int kt = 0; kt < KTMAX; ++kt)
-            if (kt < KT) st[kt] = mfma_bf16(row_frag(Kimg, kt, lane), qf, f32x4{0.f, 0.f, 0.f, 0.f});
-        float m, inv;
-        softmax_tile<KTMAX>(st, KT, maskS, scale, g, m, inv);
+            if (kt < KT) {
+                st[kt] = mfma_bf16(row_frag(Kimg, kt, lane), qf, f32x4{0.f, 0.f, 0.f, 0.f});
+                __builtin_amdgcn_sched_barrier(0);     // keep the fragment reads next to their MFMA (register pressure)
+            }
+        float lse2;
+        softmax_tile<KTMAX>(st, KT, biasS, c2, g, lse2);
         f32x4 o[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
         for (int u = 0; u < KTMAX / 2; ++u)
@@ -742,6 +782,7 @@ __global__ void __launch_bounds__(kAttThreads) attention_fwd_kernel(AttArgs a) {
                 const u32x4 pf = {pk[0], pk[1], pk[2], pk[3]};
 #pragma unroll
                 for (int dt = 0; dt < 2; ++dt) o[dt] = mfma_bf16(col_frag(VT, ldt, dt, u, lane), pf, o[dt]);
+                __builtin_amdgcn_sched_barrier(0);
             }
         if (query < a.S) {
             bf16_t *row = a.out + ((long long)b * a.S + query) * d + hd * a.dk;
@@ -753,23 +794,32 @@ __global__ void __launch_bounds__(kAttThreads) attention_fwd_kernel(AttArgs a) {
 
 inline size_t att_fwd_lds(int S) {
     const int Sp = round_up(S, 32);
-    return (size_t)(Sp * kRowLd + kDkPad * tr_ld(Sp)) * sizeof(bf16_t) + (size_t)Sp;
+    return (size_t)(Sp * kRowLd + kDkPad * tr_ld(Sp)) * sizeof(bf16_t) + (size_t)Sp * 4;
 }
 
-// Backward.  Phase A (query-major, like the forward): D_q = sum_k dP P, dS^T -> dQ; row statistics to LDS.
+// dot of two 8-element bf16 fragments
+__device__ __forceinline__ float dot8(const u32x4 &x, const u32x4 &y) {
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) s += bf16_lo(x[k]) * bf16_lo(y[k]) + bf16_hi(x[k]) * bf16_hi(y[k]);
+    return s;
+}
+
+// Backward.  With Pd = dropout(P), O = Pd V:  D_q = sum_k dP_qk P_qk = dO_q . O_q (O = the saved forward output), so no
+// pass over the keys is needed for it.
+// Phase A (query-major, like the forward): P^T recomputed, dS^T = P (dP - D) / sqrt(dk) -> dQ; lse2 and D to LDS.
 // Phase B (key-major): P and dS recomputed as [query][key] tiles -> dV^T = dO^T Pd, dK^T = Q^T dS.
-template <int KTMAX>
+template <int KTMAX, bool FULL>
 __global__ void __launch_bounds__(kAttThreads) attention_bwd_kernel(AttArgs a) {
     extern __shared__ __attribute__((aligned(16))) bf16_t smem[];
-    const int Sp = round_up(a.S, 32), KT = Sp / 16, ldt = tr_ld(Sp);
+    const int Sp = round_up(a.S, 32), KT = FULL ? KTMAX : Sp / 16, ldt = tr_ld(Sp);
     // phase A images: K rows, V rows, K^T;  phase B images: Q rows, dO rows, Q^T, dO^T (same memory)
     bf16_t *img0 = smem, *img1 = img0 + Sp * kRowLd, *tr0 = img1 + Sp * kRowLd, *tr1 = tr0 + kDkPad * ldt;
-    f32x4 *stats = reinterpret_cast<f32x4 *>(tr1 + kDkPad * ldt);       // [Sp] (row max, 1/sum, D, -)
-    uint8_t *maskS = reinterpret_cast<uint8_t *>(stats + Sp);
+    float *lseS = reinterpret_cast<float *>(tr1 + kDkPad * ldt), *DS = lseS + Sp, *biasS = DS + Sp;       // [Sp] each
     const int b = blockIdx.x / a.h, hd = blockIdx.x % a.h, d = a.h * a.dk;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, j = lane & 15, g = lane >> 4;
     const bool vec = a.dk % 8 == 0;
-    const float scale = 1.f / sqrtf((float)a.dk);
+    const float scale = 1.f / sqrtf((float)a.dk), c2 = 1.44269504088896341f * scale;
     const unsigned thr = drop_threshold(a.drop_p);
     const float ks = thr ? 1.f / (1.f - a.drop_p) : 1.f;
     const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
@@ -777,36 +827,32 @@ __global__ void __launch_bounds__(kAttThreads) attention_bwd_kernel(AttArgs a) {
     stage_head(a, b, hd, 1, Sp, img0, tr0, ldt);
     stage_head(a, b, hd, 2, Sp, img1, nullptr, 0);
     for (int k = threadIdx.x; k < Sp; k += kAttThreads) {
-        maskS[k] = k >= a.S || (a.mask && a.mask[(long long)b * a.S + k] == 1) ? 1 : 0;
-        stats[k] = zero;
+        biasS[k] = k >= a.S || (a.mask && a.mask[(long long)b * a.S + k] == 1) ? -INFINITY : 0.f;
+        lseS[k] = INFINITY;      // padded queries: p = 0 in phase B
+        DS[k] = 0.f;
     }
     __syncthreads();
+#ifndef LTR_ATT_SKIP_A      /* timing experiments only */
     for (int qt = w; qt * 16 < a.S; qt += kAttThreads / 64) {
         const int query = 16 * qt + j;
         const long long tok = (long long)b * a.S + query;
         const u32x4 qf = load8(a.qkv + tok * 3 * d + hd * a.dk, 8 * g, a.dk, vec, query < a.S);
         const u32x4 dof = load8(a.dctx + tok * d + hd * a.dk, 8 * g, a.dk, vec, query < a.S);
+        const u32x4 of = load8(a.ctx + tok * d + hd * a.dk, 8 * g, a.dk, vec, query < a.S);
+        const float D = quad_sum(dot8(dof, of));
         f32x4 st[KTMAX];
 #pragma unroll
         for (int kt = 0; kt < KTMAX; ++kt)
-            if (kt < KT) st[kt] = mfma_bf16(row_frag(img0, kt, lane), qf, zero);
-        float m, inv;
-        softmax_tile<KTMAX>(st, KT, maskS, scale, g, m, inv);
-        // D = sum_k dP P  (dP = keep ? dPd / (1-p) : 0, dPd^T = V dO^T)
-        float D = 0.f;
-        unsigned keepbits[KTMAX / 8 > 0 ? KTMAX / 8 : 1];   // 4 bits per key tile
-#pragma unroll
-        for (int kt = 0; kt < KTMAX; ++kt)
             if (kt < KT) {
-                const f32x4 dp = mfma_bf16(row_frag(img1, kt, lane), dof, zero);
-                const unsigned keep = thr ? drop_keep4(a.seed, a.stream_id, attn_idx(blockIdx.x, Sp, query, 16 * kt + 4 * g), thr) : 15u;
-                if ((kt & 7) == 0) keepbits[kt >> 3] = 0u;
-                keepbits[kt >> 3] |= keep << (4 * (kt & 7));
-#pragma unroll
-                for (int r = 0; r < 4; ++r) D += (keep >> r) & 1u ? dp[r] * ks * st[kt][r] : 0.f;
+                st[kt] = mfma_bf16(row_frag(img0, kt, lane), qf, zero);
+                __builtin_amdgcn_sched_barrier(0);
             }
-        D = quad_sum(D);
-        if (g == 0 && query < a.S) stats[query] = f32x4{m, inv, D, 0.f};
+        float lse2;
+        softmax_tile<KTMAX>(st, KT, biasS, c2, g, lse2);
+        if (g == 0 && query < a.S) {
+            lseS[query] = lse2;
+            DS[query] = D;
+        }
         f32x4 o[2] = {zero, zero};
 #pragma unroll
         for (int u = 0; u < KTMAX / 2; ++u)
@@ -815,8 +861,8 @@ __global__ void __launch_bounds__(kAttThreads) attention_bwd_kernel(AttArgs a) {
 #pragma unroll
                 for (int half = 0; half < 2; ++half) {
                     const int kt = 2 * u + half;
-                    const f32x4 dp = mfma_bf16(row_frag(img1, kt, lane), dof, zero);
-                    const unsigned keep = (keepbits[kt >> 3] >> (4 * (kt & 7))) & 15u;
+                    const f32x4 dp = mfma_bf16(row_frag(img1, kt, lane), dof, zero);     // dPd^T = V dO^T
+                    const unsigned keep = thr ? drop_keep4(a.seed, a.stream_id, attn_idx(blockIdx.x, Sp, query, 16 * kt + 4 * g), thr) : 15u;
                     f32x4 ds;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) ds[r] = st[kt][r] * (((keep >> r) & 1u ? dp[r] * ks : 0.f) - D) * scale;
@@ -826,6 +872,7 @@ __global__ void __launch_bounds__(kAttThreads) attention_bwd_kernel(AttArgs a) {
                 const u32x4 dsf = {pk[0], pk[1], pk[2], pk[3]};
 #pragma unroll
                 for (int dt = 0; dt < 2; ++dt) o[dt] = mfma_bf16(col_frag(tr0, ldt, dt, u, lane), dsf, o[dt]);
+                __builtin_amdgcn_sched_barrier(0);
             }
         if (query < a.S) {
             bf16_t *row = a.out + tok * 3 * d + hd * a.dk;
@@ -833,16 +880,18 @@ __global__ void __launch_bounds__(kAttThreads) attention_bwd_kernel(AttArgs a) {
             for (int dt = 0; dt < 2; ++dt) store4(row, 16 * dt + 4 * g, a.dk, a.dk % 4 == 0, o[dt]);
         }
     }
+#endif
     __syncthreads();
     stage_head(a, b, hd, 0, Sp, img0, tr0, ldt);
     stage_head(a, b, hd, 3, Sp, img1, tr1, ldt);
     __syncthreads();
+#ifndef LTR_ATT_SKIP_B
     for (int kt = w; kt * 16 < a.S; kt += kAttThreads / 64) {
         const int key = 16 * kt + j;
         const long long tok = (long long)b * a.S + key;
         const u32x4 kf = load8(a.qkv + tok * 3 * d + d + hd * a.dk, 8 * g, a.dk, vec, key < a.S);
         const u32x4 vf = load8(a.qkv + tok * 3 * d + 2 * d + hd * a.dk, 8 * g, a.dk, vec, key < a.S);
-        const bool masked = maskS[key < Sp ? key : 0] != 0;
+        const bool masked = biasS[key] != 0.f;
         f32x4 dv[2] = {zero, zero}, dkk[2] = {zero, zero};
         for (int u = 0; u < KT / 2; ++u) {
             unsigned pk[4], dk4[4];
@@ -851,15 +900,15 @@ __global__ void __launch_bounds__(kAttThreads) attention_bwd_kernel(AttArgs a) {
                 const int qt = 2 * u + half;
                 const f32x4 s = mfma_bf16(row_frag(img0, qt, lane), kf, zero);      // S[query 16 qt + 4 g + r][key]
                 const f32x4 dpd = mfma_bf16(row_frag(img1, qt, lane), vf, zero);    // dPd[query][key]
+                const f32x4 l4 = *reinterpret_cast<const f32x4 *>(lseS + 16 * qt + 4 * g);
+                const f32x4 d4 = *reinterpret_cast<const f32x4 *>(DS + 16 * qt + 4 * g);
                 f32x4 pd, ds;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int query = 16 * qt + 4 * g + r;
-                    const f32x4 sq = stats[query];
-                    const float p = masked ? 0.f : __expf(s[r] * scale - sq[0]) * sq[1];
-                    const bool keep = thr ? drop_keep(a.seed, a.stream_id, attn_idx(blockIdx.x, Sp, query, key), thr) : true;
+                    const float p = masked ? 0.f : __builtin_amdgcn_exp2f(s[r] * c2 - l4[r]);
+                    const bool keep = thr ? drop_keep(a.seed, a.stream_id, attn_idx(blockIdx.x, Sp, 16 * qt + 4 * g + r, key), thr) : true;
                     pd[r] = keep ? p * ks : 0.f;
-                    ds[r] = p * ((keep ? dpd[r] * ks : 0.f) - sq[2]) * scale;
+                    ds[r] = p * ((keep ? dpd[r] * ks : 0.f) - d4[r]) * scale;
                 }
                 pk[2 * half] = pack_bf16(pd[0], pd[1]);
                 pk[2 * half + 1] = pack_bf16(pd[2], pd[3]);
@@ -882,24 +931,35 @@ __global__ void __launch_bounds__(kAttThreads) attention_bwd_kernel(AttArgs a) {
             }
         }
     }
+#endif
 }
 
 inline size_t att_bwd_lds(int S) {
     const int Sp = round_up(S, 32);
-    return (size_t)(2 * Sp * kRowLd + 2 * kDkPad * tr_ld(Sp)) * sizeof(bf16_t) + (size_t)Sp * 16 + (size_t)Sp;
+    return (size_t)(2 * Sp * kRowLd + 2 * kDkPad * tr_ld(Sp)) * sizeof(bf16_t) + (size_t)Sp * 12;
 }
 
-template <class K>
-int set_lds_attr(K kernel, size_t lds, bool (&done)[64]) {
+// one instantiation (and one set of per-device attribute flags) per kernel variant
+template <int KTMAX, bool FULL, bool BWD>
+int launch_att_tagged(const AttArgs &a, size_t lds, hipStream_t stream) {
+    static bool done[64] = {};
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = -1;
+    auto kernel = BWD ? attention_bwd_kernel<KTMAX, FULL> : attention_fwd_kernel<KTMAX, FULL>;
     if (dev < 0 || !done[dev]) {
         hipError_t e = hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return (int)e;
         if (dev >= 0) done[dev] = true;
     }
-    (void)lds;
-    return 0;
+    hipLaunchKernelGGL(kernel, dim3(a.B * a.h), dim3(kAttThreads), lds, stream, a);
+    return status();
+}
+template <bool BWD>
+int dispatch_att(const AttArgs &a, size_t lds, hipStream_t stream) {
+    const int Sp = round_up(a.S, 32);
+    if (Sp <= 128) return Sp == 128 ? launch_att_tagged<8, true, BWD>(a, lds, stream) : launch_att_tagged<8, false, BWD>(a, lds, stream);
+    if (Sp <= 256) return Sp == 256 ? launch_att_tagged<16, true, BWD>(a, lds, stream) : launch_att_tagged<16, false, BWD>(a, lds, stream);
+    return Sp == 512 ? launch_att_tagged<32, true, BWD>(a, lds, stream) : launch_att_tagged<32, false, BWD>(a, lds, stream);
 }
 
 int check_att(const uint16_t *qkv, const void *other, int B, int S, int h, int dk, float p) {
@@ -952,8 +1012,14 @@ int ltr_enc_sum_partials(const float *parts, int nsplit, int64_t n, int accumula
     if (!parts || !out) return LTR_ERR_NULL;
     if (nsplit < 1 || n < 0) return LTR_ERR_SHAPE;
     if (n == 0) return LTR_OK;
-    hipLaunchKernelGGL(sum_partials_kernel, dim3(elt_grid(n, 256)), dim3(256), 0, (hipStream_t)stream, parts, nsplit, (long long)n,
-                       accumulate, out);
+    hipStream_t s = (hipStream_t)stream;
+    // few outputs: spend the threads on the split axis; many outputs: one thread per output
+    if (n >= 65536 || nsplit < 8)
+        hipLaunchKernelGGL(sum_partials_kernel<1>, dim3(elt_grid(n, 256)), dim3(256), 0, s, parts, nsplit, (long long)n, accumulate, out);
+    else if (n >= 4096)
+        hipLaunchKernelGGL(sum_partials_kernel<4>, dim3(elt_grid(n, 64)), dim3(256), 0, s, parts, nsplit, (long long)n, accumulate, out);
+    else
+        hipLaunchKernelGGL(sum_partials_kernel<16>, dim3(elt_grid(n, 16)), dim3(256), 0, s, parts, nsplit, (long long)n, accumulate, out);
     return status();
 }
 
@@ -1020,36 +1086,18 @@ int ltr_enc_attention_fwd(const uint16_t *qkv, const uint8_t *mask, int B, int S
                           uint64_t seed, int stream_id, uint16_t *ctx, void *stream) {
     if (int rc = check_att(qkv, ctx, B, S, h, dk, drop_p)) return rc;
     if (B == 0) return LTR_OK;
-    AttArgs a{qkv, nullptr, mask, ctx, B, S, h, dk, drop_p, (unsigned long long)seed, stream_id};
-    const size_t lds = att_fwd_lds(S);
-    static bool done16[64] = {}, done32[64] = {};
-    if (S <= 256) {
-        if (int rc = set_lds_attr(attention_fwd_kernel<16>, lds, done16)) return rc;
-        hipLaunchKernelGGL(attention_fwd_kernel<16>, dim3(B * h), dim3(kAttThreads), lds, (hipStream_t)stream, a);
-    } else {
-        if (int rc = set_lds_attr(attention_fwd_kernel<32>, lds, done32)) return rc;
-        hipLaunchKernelGGL(attention_fwd_kernel<32>, dim3(B * h), dim3(kAttThreads), lds, (hipStream_t)stream, a);
-    }
-    return status();
+    AttArgs a{qkv, nullptr, nullptr, mask, ctx, B, S, h, dk, drop_p, (unsigned long long)seed, stream_id};
+    return dispatch_att<false>(a, att_fwd_lds(S), (hipStream_t)stream);
 }
 
-int ltr_enc_attention_bwd(const uint16_t *qkv, const uint16_t *dctx, const uint8_t *mask, int B, int S, int h, int dk,
-                          float drop_p, uint64_t seed, int stream_id, uint16_t *dqkv, void *stream) {
-    if (!dctx) return LTR_ERR_NULL;
+int ltr_enc_attention_bwd(const uint16_t *qkv, const uint16_t *ctx, const uint16_t *dctx, const uint8_t *mask, int B, int S, int h,
+                          int dk, float drop_p, uint64_t seed, int stream_id, uint16_t *dqkv, void *stream) {
+    if (!dctx || !ctx) return LTR_ERR_NULL;
     if (int rc = check_att(qkv, dqkv, B, S, h, dk, drop_p)) return rc;
-    if ((uintptr_t)dctx & 15u) return LTR_ERR_ALIGN;
+    if (((uintptr_t)dctx & 15u) || ((uintptr_t)ctx & 15u)) return LTR_ERR_ALIGN;
     if (B == 0) return LTR_OK;
-    AttArgs a{qkv, dctx, mask, dqkv, B, S, h, dk, drop_p, (unsigned long long)seed, stream_id};
-    const size_t lds = att_bwd_lds(S);
-    static bool done16[64] = {}, done32[64] = {};
-    if (S <= 256) {
-        if (int rc = set_lds_attr(attention_bwd_kernel<16>, lds, done16)) return rc;
-        hipLaunchKernelGGL(attention_bwd_kernel<16>, dim3(B * h), dim3(kAttThreads), lds, (hipStream_t)stream, a);
-    } else {
-        if (int rc = set_lds_attr(attention_bwd_kernel<32>, lds, done32)) return rc;
-        hipLaunchKernelGGL(attention_bwd_kernel<32>, dim3(B * h), dim3(kAttThreads), lds, (hipStream_t)stream, a);
-    }
-    return status();
+    AttArgs a{qkv, dctx, ctx, mask, dqkv, B, S, h, dk, drop_p, (unsigned long long)seed, stream_id};
+    return dispatch_att<true>(a, att_bwd_lds(S), (hipStream_t)stream);
 }
 
 int ltr_enc_score_fwd(const float *x, const float *a, const float *b, const float *w, const float *bias, int64_t T, int d,

@@ -89,8 +89,8 @@ _NBLK = 512     # workgroups (= partial rows) of the column-sum style reductions
 
 def _dw_splits(M, N, K):
     tiles = ((M + 127) // 128) * ((N + 127) // 128)
-    s = max(1, min(64, (1024 + tiles - 1) // tiles))
-    return max(1, min(s, (K + 511) // 512))
+    s = max(1, min(32, (512 + tiles - 1) // tiles))
+    return max(1, min(s, (K + 1023) // 1024))
 
 
 def _weight_grad(dy, x, T, n_out, n_in):
@@ -326,7 +326,7 @@ class EncoderScores(torch.autograd.Function):
                     dctx = torch.empty((T, d), dtype=_U16, device=dev)
                     gemm(dyo, wo16, T, d, d, b_kmajor=True, Cb=dctx)
                     dqkv = torch.empty((T, 3 * d), dtype=_U16, device=dev)
-                    check(lib().ltr_enc_attention_bwd(_ptr(qkv), _ptr(dctx), _ptr(st["mask_u8"]), B, S, h, dk, p_enc, int(seed),
+                    check(lib().ltr_enc_attention_bwd(_ptr(qkv), _ptr(ctxb), _ptr(dctx), _ptr(st["mask_u8"]), B, S, h, dk, p_enc, int(seed),
                                                       stream_attn(l), _ptr(dqkv), _stream()), "ltr_enc_attention_bwd")
                     gbqkv = _colsum(dqkv, T, 3 * d)
                     gWqkv = _weight_grad(dqkv, n1, T, 3 * d, d)
