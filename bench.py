@@ -136,7 +136,9 @@ def secondary_lines(a):
       bf16x3 : the split-precision variant of the pipeline (same C ABI, LTR_LIB) on the headline workload -- reported next to
                the exact-fp32 headline, not instead of it;
       two64  : the 136-64-1 two-layer scorer BASELINE.json configs[0] names, the configuration the 60 % HBM target was
-               written for (exact-fp32 library)."""
+               written for (exact-fp32 library);
+      config5: BASELINE.json configs[4] -- architeture/transformer.py scorer (make_model: FC 136->128, 6 encoder blocks,
+               8 heads, d_ff 2048, dropout 0.1) + approxNDCG, slate 256, bf16 operands (tools/bench_encoder.py)."""
     import subprocess
     here = os.path.abspath(__file__)
     variant = os.path.join(ROOT, "nn-with-pytorch-personalized-losses_amd", "ltr_mi355x", "libltr_mi355x_bf16x3.so")
@@ -157,6 +159,16 @@ def secondary_lines(a):
                          "roofline": {k: j["roofline"][k] for k in ("achieved", "frac", "kernel_ms", "hbm_achieved_GBps", "hbm_frac_of_8TBps")}}
         except Exception as e:          # a secondary line must never take the headline down
             out[name] = {"error": f"{type(e).__name__}: {e}"[:200]}
+    try:
+        enc = os.path.join(ROOT, "tools", "bench_encoder.py")
+        r = subprocess.run([sys.executable, enc, "--batch", "256", "--steps", "10", "--warmup", "3"], capture_output=True, text=True,
+                           timeout=600)
+        j = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+        out["config5"] = {"value": j["slates_per_s"], "unit": "slates/s", "ms_per_step": j["ms_per_step"], "workload": j["workload"],
+                          "dtype": "bf16", "roofline": {"bound": "mfma", "achieved": j["tflops"], "peak": 2500.0, "unit": "TFLOP/s",
+                                                        "frac": j["frac_of_bf16_mfma_peak"]}}
+    except Exception as e:
+        out["config5"] = {"error": f"{type(e).__name__}: {e}"[:200]}
     return out
 
 

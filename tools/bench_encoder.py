@@ -76,7 +76,7 @@ def main():
                                   f"train mode, {B} slates x {S} x {F} per step, fwd+loss+bwd+Adam",
                       "slates_per_s": round(B / dt, 1), "ms_per_step": round(dt * 1e3, 3), "flops_per_slate": fl,
                       "tflops": round(B * fl / dt / 1e12, 2), "frac_of_bf16_mfma_peak": round(B * fl / dt / 2.5e15, 4),
-                      "final_loss": round(float(loss), 5), "max_mem_GB": round(torch.cuda.max_memory_allocated() / 2 ** 30, 2)}))
+                      "final_loss": round(float(loss.detach()), 5), "max_mem_GB": round(torch.cuda.max_memory_allocated() / 2 ** 30, 2)}))
 
 
 if __name__ == "__main__":
