@@ -90,6 +90,26 @@ int ltr_enc_attention_fwd(const uint16_t *qkv, const uint8_t *mask, int B, int S
 int ltr_enc_attention_bwd(const uint16_t *qkv, const uint16_t *ctx, const uint16_t *dctx, const uint8_t *mask, int B, int S, int h,
                           int dk, float drop_p, uint64_t seed, int stream_id, uint16_t *dqkv, void *stream);
 
+/* ---- PositionwiseFeedForward + its residual tail (transformer.py:215-237, :113-114) without a [T][d_ff] tensor in HBM:
+ * the hidden activation is produced 128 units at a time in registers and recomputed in the backward.
+ *   forward    x2 = x1 + dropout(dropout(relu(n2 W1^T + b1)) W2^T + b2)      (streams: stream_hidden idx = t*dff + h,
+ *                                                                              stream_out idx = t*d + c -- the same
+ *                                                                              streams ltr_enc_gemm_bf16 would use)
+ *   backward X dn2 [T][d] fp32 = ((dy W2) gated by the recomputed activation) W1,  dy [T][d] bf16 = d loss / d (FFN output
+ *              before the output dropout's inverse, i.e. what ltr_enc_drop_cast_colsum produces)
+ *   backward W per-range partials dw1 [nsplit][dff][d], dw2 [nsplit][d][dff], db1 [nsplit][dff] (reduce with
+ *              ltr_enc_sum_partials); workgroup = (128-unit chunk, token range).
+ * n2 [T][d], w1 [dff][d], w2 [d][dff] bf16; b1, b2, x1, x2 fp32.  d in {64, 128}, dff a multiple of 128
+ * (ltr_enc_ffn_supported); other shapes use the GEMM entry point. */
+int ltr_enc_ffn_supported(int d, int dff);
+int ltr_enc_ffn_fwd(const uint16_t *n2, const uint16_t *w1, const float *b1, const uint16_t *w2, const float *b2, const float *x1,
+                    int64_t T, int d, int dff, float drop_p, uint64_t seed, int stream_hidden, int stream_out, float *x2, void *stream);
+int ltr_enc_ffn_bwd_x(const uint16_t *n2, const uint16_t *w1, const float *b1, const uint16_t *w2, const uint16_t *dy, int64_t T, int d,
+                      int dff, float drop_p, uint64_t seed, int stream_hidden, float *dn2, void *stream);
+int ltr_enc_ffn_bwd_w(const uint16_t *n2, const uint16_t *w1, const float *b1, const uint16_t *w2, const uint16_t *dy, int64_t T, int d,
+                      int dff, float drop_p, uint64_t seed, int stream_hidden, int nsplit, float *dw1_parts, float *dw2_parts,
+                      float *db1_parts, void *stream);
+
 /* ---- Encoder.norm + OutputLayer.w_1 with d_output = 1 (transformer.py:59, multiLayer.py:104-113):
  *   scores[t] = w . LN(x[t]) + bias     (norm: 0 = none, 1 = transformer.py LayerNorm, 2 = nn.LayerNorm)
  * `bias` is a device pointer to one float.  The listwise loss then runs on scores [B][S] (ltr_mi355x.h). */

@@ -609,6 +609,372 @@ int launch_gemm(const ltr_gemm_desc &g, hipStream_t stream) {
     return status();
 }
 
+// ------------------------------------------------------------------------------------------- fused FFN
+// PositionwiseFeedForward (transformer.py:215-237) + its SublayerConnection tail, WITHOUT a [T][d_ff] tensor in HBM:
+// with d_model = 128 every FFN GEMM has at most 64 FLOP per byte of that tensor, so the unfused path is bound by
+// writing and re-reading it (section 4.5 of DESIGN.md).  Here the hidden activation lives in registers only: it is
+// produced 128 hidden units at a time in the accumulator layout whose registers ARE the next product's MFMA operand
+// (k-slot permutation absorbed by how the weights are read from LDS), and the backward recomputes it.
+//   forward   : x2 = x1 + drop(relu-drop(n2 W1^T + b1) W2^T + b2)              wave = 32 tokens, loops over d_ff chunks
+//   backward X: dn2 = ((dy W2) gated) W1                                        same partition
+//   backward W: dW1, dW2, db1 partials                                          workgroup = (chunk, token range), wave = 16 hidden
+// D = d_model (multiple of 32, <= 128), d_ff multiple of 128.
+constexpr int kFfnThreads = 512;
+constexpr int kFfnChunk = 128;
+constexpr int kFfnTok = 256;        // tokens per workgroup (forward / backward X)
+
+struct FfnArgs {
+    const bf16_t *n2, *w1, *w2, *dy;
+    const float *b1, *b2, *x1;
+    long long T;
+    int dff;
+    float p;
+    unsigned long long seed;
+    int stream_hidden, stream_out;
+    float *out;            // fwd: x2 [T][D];  bwd X: dn2 [T][D]
+    float *dw1, *dw2, *db1;   // bwd W partials [nsplit][dff][D], [nsplit][D][dff], [nsplit][dff]
+    int nsplit;
+};
+
+// cooperative copy of a [ROWS][COLS] bf16 block (global row stride ld) into an LDS image with row stride LD, in two
+// halves so that the global latency hides under the MFMA work in between: ffn_load issues this thread's 16-byte pieces
+// into registers (rows >= row_lim read as zero), ffn_store writes them to the image.
+template <int ROWS, int COLS>
+__device__ __forceinline__ void ffn_load(const bf16_t *__restrict__ src, long long ld, long long row_lim, u32x4 (&r)[ROWS * COLS / 8 / kFfnThreads]) {
+    constexpr int CPR = COLS / 8;
+    static_assert(ROWS * CPR % kFfnThreads == 0, "whole pieces per thread");
+#pragma unroll
+    for (int i = 0; i < ROWS * CPR / kFfnThreads; ++i) {
+        const int p = threadIdx.x + kFfnThreads * i, row = p / CPR, ch = p - row * CPR;
+        const u32x4 z = {0u, 0u, 0u, 0u};
+        r[i] = row < row_lim ? *reinterpret_cast<const u32x4 *>(src + (long long)row * ld + 8 * ch) : z;
+    }
+}
+template <int ROWS, int COLS, int LD>
+__device__ __forceinline__ void ffn_store(bf16_t *img, const u32x4 (&r)[ROWS * COLS / 8 / kFfnThreads]) {
+    constexpr int CPR = COLS / 8;
+#pragma unroll
+    for (int i = 0; i < ROWS * CPR / kFfnThreads; ++i) {
+        const int p = threadIdx.x + kFfnThreads * i, row = p / CPR, ch = p - row * CPR;
+        *reinterpret_cast<u32x4 *>(img + row * LD + 8 * ch) = r[i];
+    }
+}
+
+// the same copy one piece at a time (no register array): for the kernels that have no registers to spare
+template <int ROWS, int COLS, int LD>
+__device__ __forceinline__ void ffn_stage(bf16_t *img, const bf16_t *__restrict__ src, long long ld, long long row_lim) {
+    constexpr int CPR = COLS / 8;
+#pragma unroll 1
+    for (int p = threadIdx.x; p < ROWS * CPR; p += kFfnThreads) {
+        const int row = p / CPR, ch = p - row * CPR;
+        const u32x4 z = {0u, 0u, 0u, 0u};
+        *reinterpret_cast<u32x4 *>(img + row * LD + 8 * ch) = row < row_lim ? *reinterpret_cast<const u32x4 *>(src + (long long)row * ld + 8 * ch) : z;
+    }
+}
+
+// B-operand fragments of a token tile straight from global: token = lane & 15, k-step k of 32 features.
+//   SPLIT = false: features 32 k + 8 g .. + 7 (pairs with ds_read_b128 row fragments)
+//   SPLIT = true : features 32 k + 4 g .. + 3 and 32 k + 16 + 4 g .. + 3 (pairs with transposed reads)
+template <bool SPLIT>
+__device__ __forceinline__ u32x4 tok_frag(const bf16_t *__restrict__ base, long long tok, long long T, int D, int k, int g) {
+    u32x4 r = {0u, 0u, 0u, 0u};
+    if (tok >= T) return r;
+    const bf16_t *row = base + tok * D + 32 * k;
+    if (!SPLIT) return *reinterpret_cast<const u32x4 *>(row + 8 * g);
+    const u32x2 lo = *reinterpret_cast<const u32x2 *>(row + 4 * g), hi = *reinterpret_cast<const u32x2 *>(row + 16 + 4 * g);
+    return u32x4{lo[0], lo[1], hi[0], hi[1]};
+}
+
+// hidden pre-activations of the wave's two token tiles for hidden tile ht of the chunk in LDS:
+// z[tt][r] = (W1c x^T)[hidden 16 ht + 4 q + r][token (lane & 15) of tile tt]
+template <int D, int LD>
+__device__ __forceinline__ void ffn_z(const bf16_t *w1img, int ht, const u32x4 (&xf)[2][D / 32], f32x4 (&z)[2], int lane) {
+    z[0] = z[1] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < D / 32; ++k) {
+        const u32x4 a = *reinterpret_cast<const u32x4 *>(w1img + (16 * ht + (lane & 15)) * LD + 32 * k + 8 * (lane >> 4));
+        z[0] = mfma_bf16(a, xf[0][k], z[0]);
+        z[1] = mfma_bf16(a, xf[1][k], z[1]);
+    }
+}
+
+template <int D>
+__global__ void __launch_bounds__(kFfnThreads) ffn_fwd_kernel(FfnArgs a) {
+    extern __shared__ __attribute__((aligned(16))) bf16_t smem[];
+    constexpr int DK = D / 32, DT = D / 16, LD1 = D + 8, LD2 = kFfnChunk + 8;
+    constexpr int IMG = kFfnChunk * LD1 + D * LD2;           // W1c [128][LD1] then W2c [D][LD2]
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, j = lane & 15, q = lane >> 4;
+    const long long tok0 = (long long)blockIdx.x * kFfnTok + 32 * w;
+    const unsigned thr = drop_threshold(a.p);
+    const float ks = thr ? 1.f / (1.f - a.p) : 1.f;
+    u32x4 xf[2][DK];
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+        for (int k = 0; k < DK; ++k) xf[tt][k] = tok_frag<false>(a.n2, tok0 + 16 * tt + j, a.T, D, k, q);
+    f32x4 y[DT][2];
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) y[dt][0] = y[dt][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int nc = a.dff / kFfnChunk;
+    u32x4 r1[kFfnChunk * D / 8 / kFfnThreads], r2[D * kFfnChunk / 8 / kFfnThreads];
+    ffn_load<kFfnChunk, D>(a.w1, D, kFfnChunk, r1);
+    ffn_load<D, kFfnChunk>(a.w2, a.dff, D, r2);
+    ffn_store<kFfnChunk, D, LD1>(smem, r1);
+    ffn_store<D, kFfnChunk, LD2>(smem + kFfnChunk * LD1, r2);
+    __syncthreads();
+    for (int c = 0; c < nc; ++c) {
+        const bf16_t *w1img = smem + (c & 1) * IMG, *w2img = w1img + kFfnChunk * LD1;
+        if (c + 1 < nc) {       // next chunk into the other buffer (its last readers passed the barrier below)
+            bf16_t *nx = smem + ((c + 1) & 1) * IMG;
+            ffn_load<kFfnChunk, D>(a.w1 + (long long)(c + 1) * kFfnChunk * D, D, kFfnChunk, r1);
+            ffn_load<D, kFfnChunk>(a.w2 + (long long)(c + 1) * kFfnChunk, a.dff, D, r2);
+            ffn_store<kFfnChunk, D, LD1>(nx, r1);
+            ffn_store<D, kFfnChunk, LD2>(nx + kFfnChunk * LD1, r2);
+        }
+        u32x2 hb[8][2];
+#pragma unroll
+        for (int ht = 0; ht < 8; ++ht) {
+            f32x4 z[2];
+            ffn_z<D, LD1>(w1img, ht, xf, z, lane);
+            const int h0 = c * kFfnChunk + 16 * ht + 4 * q;
+            const f32x4 bias = *reinterpret_cast<const f32x4 *>(a.b1 + h0);
+#pragma unroll
+            for (int tt = 0; tt < 2; ++tt) {
+                f32x4 v = z[tt] + bias;
+                const unsigned keep = thr ? drop_keep4(a.seed, a.stream_hidden, (unsigned long long)(tok0 + 16 * tt + j) * a.dff + h0, thr) : 15u;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = (keep >> r) & 1u ? fmaxf(v[r], 0.f) * ks : 0.f;
+                hb[ht][tt] = u32x2{pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3])};
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const u32x4 b0 = {hb[2 * u][0][0], hb[2 * u][0][1], hb[2 * u + 1][0][0], hb[2 * u + 1][0][1]};
+            const u32x4 b1v = {hb[2 * u][1][0], hb[2 * u][1][1], hb[2 * u + 1][1][0], hb[2 * u + 1][1][1]};
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) {
+                const bf16_t *pr = w2img + (16 * dt + j) * LD2 + 32 * u + 4 * q;
+                const u32x2 lo = *reinterpret_cast<const u32x2 *>(pr), hi = *reinterpret_cast<const u32x2 *>(pr + 16);
+                const u32x4 af = {lo[0], lo[1], hi[0], hi[1]};
+                y[dt][0] = mfma_bf16(af, b0, y[dt][0]);
+                y[dt][1] = mfma_bf16(af, b1v, y[dt][1]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        __syncthreads();
+    }
+    // y^T tiles: lane = token, registers = 4 consecutive d
+    const unsigned thro = drop_threshold(a.p);
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt) {
+        const long long tok = tok0 + 16 * tt + j;
+        if (tok >= a.T) continue;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) {
+            const int d0 = 16 * dt + 4 * q;
+            f32x4 v = y[dt][tt] + *reinterpret_cast<const f32x4 *>(a.b2 + d0);
+            if (thro) {
+                const unsigned keep = drop_keep4(a.seed, a.stream_out, (unsigned long long)tok * D + d0, thro);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = (keep >> r) & 1u ? v[r] * ks : 0.f;
+            }
+            v += *reinterpret_cast<const f32x4 *>(a.x1 + tok * D + d0);
+            *reinterpret_cast<f32x4 *>(a.out + tok * D + d0) = v;
+        }
+    }
+}
+
+template <int D>
+__global__ void __launch_bounds__(kFfnThreads) ffn_bwd_x_kernel(FfnArgs a) {
+    extern __shared__ __attribute__((aligned(16))) bf16_t smem[];
+    constexpr int DK = D / 32, DT = D / 16, LD1 = D + 16, LD2 = kFfnChunk + 16;   // both images are also read transposed
+    constexpr int IMG = kFfnChunk * LD1 + D * LD2;
+    static_assert((LD1 / 2) % 64 == 8 || (LD1 / 2) % 64 == 24 || (LD1 / 2) % 64 == 40 || (LD1 / 2) % 64 == 56, "transposed-read stride");
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, j = lane & 15, q = lane >> 4;
+    const long long tok0 = (long long)blockIdx.x * kFfnTok + 32 * w;
+    const unsigned thr = drop_threshold(a.p);
+    const float ks = thr ? 1.f / (1.f - a.p) : 1.f;
+    u32x4 xf[2][DK], dyf[2][DK];
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+        for (int k = 0; k < DK; ++k) {
+            xf[tt][k] = tok_frag<false>(a.n2, tok0 + 16 * tt + j, a.T, D, k, q);
+            dyf[tt][k] = tok_frag<true>(a.dy, tok0 + 16 * tt + j, a.T, D, k, q);
+        }
+    f32x4 dn[DT][2];
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) dn[dt][0] = dn[dt][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int nc = a.dff / kFfnChunk;
+    ffn_stage<kFfnChunk, D, LD1>(smem, a.w1, D, kFfnChunk);
+    ffn_stage<D, kFfnChunk, LD2>(smem + kFfnChunk * LD1, a.w2, a.dff, D);
+    __syncthreads();
+    for (int c = 0; c < nc; ++c) {
+        const bf16_t *w1img = smem + (c & 1) * IMG, *w2img = w1img + kFfnChunk * LD1;
+        if (c + 1 < nc) {       // next chunk into the other buffer (its last readers passed the barrier below)
+            bf16_t *nx = smem + ((c + 1) & 1) * IMG;
+            ffn_stage<kFfnChunk, D, LD1>(nx, a.w1 + (long long)(c + 1) * kFfnChunk * D, D, kFfnChunk);
+            ffn_stage<D, kFfnChunk, LD2>(nx + kFfnChunk * LD1, a.w2 + (long long)(c + 1) * kFfnChunk, a.dff, D);
+        }
+        // gate bits: the hidden unit is alive (relu) and kept (dropout)
+        unsigned gate[2] = {0u, 0u};          // bit 4 ht + r of word tt
+        {
+#pragma unroll
+            for (int ht = 0; ht < 8; ++ht) {
+                f32x4 z[2];
+                ffn_z<D, LD1>(w1img, ht, xf, z, lane);
+                const int h0 = c * kFfnChunk + 16 * ht + 4 * q;
+                const f32x4 bias = *reinterpret_cast<const f32x4 *>(a.b1 + h0);
+#pragma unroll
+                for (int tt = 0; tt < 2; ++tt) {
+                    const unsigned keep = thr ? drop_keep4(a.seed, a.stream_hidden, (unsigned long long)(tok0 + 16 * tt + j) * a.dff + h0, thr) : 15u;
+                    unsigned bits = 0u;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        // alive iff the FORWARD's stored bf16 activation is > 0 (same test as the unfused gate)
+                        const float hv = from_bf16(to_bf16(fmaxf(z[tt][r] + bias[r], 0.f) * ks));
+                        bits |= (hv > 0.f ? 1u : 0u) << r;
+                    }
+                    gate[tt] |= (bits & keep) << (4 * ht);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        // dh^T = W2c^T dy^T (A: transposed read of the [d][hidden] image), gated -> dz^T as the next B operand
+        u32x2 dzb[8][2];
+#pragma unroll
+        for (int ht = 0; ht < 8; ++ht) {
+            f32x4 dh0 = {0.f, 0.f, 0.f, 0.f}, dh1 = dh0;
+#pragma unroll
+            for (int k = 0; k < DK; ++k) {
+                const u32x4 af = tr_frag<LD2>(w2img, 32 * k, ht, lane);
+                dh0 = mfma_bf16(af, dyf[0][k], dh0);
+                dh1 = mfma_bf16(af, dyf[1][k], dh1);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                dh0[r] = (gate[0] >> (4 * ht + r)) & 1u ? dh0[r] * ks : 0.f;
+                dh1[r] = (gate[1] >> (4 * ht + r)) & 1u ? dh1[r] * ks : 0.f;
+            }
+            dzb[ht][0] = u32x2{pack_bf16(dh0[0], dh0[1]), pack_bf16(dh0[2], dh0[3])};
+            dzb[ht][1] = u32x2{pack_bf16(dh1[0], dh1[1]), pack_bf16(dh1[2], dh1[3])};
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // dn2^T += W1c^T dz^T (A: transposed read of the [hidden][d] image)
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const u32x4 b0 = {dzb[2 * u][0][0], dzb[2 * u][0][1], dzb[2 * u + 1][0][0], dzb[2 * u + 1][0][1]};
+            const u32x4 b1v = {dzb[2 * u][1][0], dzb[2 * u][1][1], dzb[2 * u + 1][1][0], dzb[2 * u + 1][1][1]};
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) {
+                const u32x4 af = tr_frag<LD1>(w1img, 32 * u, dt, lane);
+                dn[dt][0] = mfma_bf16(af, b0, dn[dt][0]);
+                dn[dt][1] = mfma_bf16(af, b1v, dn[dt][1]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt) {
+        const long long tok = tok0 + 16 * tt + j;
+        if (tok >= a.T) continue;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) *reinterpret_cast<f32x4 *>(a.out + tok * D + 16 * dt + 4 * q) = dn[dt][tt];
+    }
+}
+
+// workgroup = (chunk c = blockIdx.x, token range blockIdx.y); wave w = hidden units 16 w .. 16 w + 15 of the chunk
+template <int D>
+__global__ void __launch_bounds__(kFfnThreads) ffn_bwd_w_kernel(FfnArgs a) {
+    extern __shared__ __attribute__((aligned(16))) bf16_t smem[];
+    constexpr int DK = D / 32, DT = D / 16, LD = D + 16, TOK = 128, IMG = 2 * TOK * LD;   // n2 tile then dy tile, [token][d]
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, j = lane & 15, q = lane >> 4;
+    const int c = blockIdx.x, hid = c * kFfnChunk + 16 * w + j;          // this lane's hidden unit (as a column)
+    const unsigned thr = drop_threshold(a.p);
+    const float ks = thr ? 1.f / (1.f - a.p) : 1.f;
+    // token range of this workgroup, whole 128-token tiles
+    const long long tiles = (a.T + TOK - 1) / TOK, per = (tiles + gridDim.y - 1) / gridDim.y;
+    const long long t_beg = (long long)blockIdx.y * per, t_end = t_beg + per < tiles ? t_beg + per : tiles;
+    // B operands of the two recomputed products, constant for the wave: W1[hid][d 32k + 8g ..], W2[d 32k + 8g ..][hid]
+    u32x4 w1f[DK], w2f[DK];
+#pragma unroll
+    for (int k = 0; k < DK; ++k) {
+        w1f[k] = *reinterpret_cast<const u32x4 *>(a.w1 + (long long)hid * D + 32 * k + 8 * q);
+        unsigned short e[8];
+#pragma unroll
+        for (int x = 0; x < 8; ++x) e[x] = a.w2[(long long)(32 * k + 8 * q + x) * a.dff + hid];
+        w2f[k] = u32x4{(unsigned)e[0] | ((unsigned)e[1] << 16), (unsigned)e[2] | ((unsigned)e[3] << 16),
+                       (unsigned)e[4] | ((unsigned)e[5] << 16), (unsigned)e[6] | ((unsigned)e[7] << 16)};
+    }
+    const float b1v = a.b1[hid];
+    f32x4 dw2[DT], dw1[DT];
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) dw2[dt] = dw1[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float db1 = 0.f;
+    if (t_beg < t_end) {
+        ffn_stage<TOK, D, LD>(smem, a.n2 + t_beg * TOK * D, D, a.T - t_beg * TOK);
+        ffn_stage<TOK, D, LD>(smem + TOK * LD, a.dy + t_beg * TOK * D, D, a.T - t_beg * TOK);
+    }
+    __syncthreads();
+    for (long long t = t_beg; t < t_end; ++t) {
+        const bf16_t *ximg = smem + ((t - t_beg) & 1) * IMG, *dyimg = ximg + TOK * LD;
+        if (t + 1 < t_end) {
+            bf16_t *nx = smem + ((t + 1 - t_beg) & 1) * IMG;
+            ffn_stage<TOK, D, LD>(nx, a.n2 + (t + 1) * TOK * D, D, a.T - (t + 1) * TOK);
+            ffn_stage<TOK, D, LD>(nx + TOK * LD, a.dy + (t + 1) * TOK * D, D, a.T - (t + 1) * TOK);
+        }
+        u32x2 hb[8], dzb[8];
+#pragma unroll
+        for (int tt = 0; tt < 8; ++tt) {
+            f32x4 z = {0.f, 0.f, 0.f, 0.f}, dh = z;        // rows = tokens 16 tt + 4 q + r, column = this lane's hidden unit
+#pragma unroll
+            for (int k = 0; k < DK; ++k) {
+                const u32x4 ax = *reinterpret_cast<const u32x4 *>(ximg + (16 * tt + j) * LD + 32 * k + 8 * q);
+                const u32x4 ay = *reinterpret_cast<const u32x4 *>(dyimg + (16 * tt + j) * LD + 32 * k + 8 * q);
+                z = mfma_bf16(ax, w1f[k], z);
+                dh = mfma_bf16(ay, w2f[k], dh);
+            }
+            f32x4 h, dz;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const long long tok = t * TOK + 16 * tt + 4 * q + r;
+                const bool keep = thr ? drop_keep(a.seed, a.stream_hidden, (unsigned long long)tok * a.dff + hid, thr) : true;
+                h[r] = keep && tok < a.T ? from_bf16(to_bf16(fmaxf(z[r] + b1v, 0.f) * ks)) : 0.f;
+                dz[r] = h[r] > 0.f ? from_bf16(to_bf16(dh[r] * ks)) : 0.f;
+                db1 += dz[r];
+            }
+            hb[tt] = u32x2{pack_bf16(h[0], h[1]), pack_bf16(h[2], h[3])};
+            dzb[tt] = u32x2{pack_bf16(dz[0], dz[1]), pack_bf16(dz[2], dz[3])};
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {        // 32 tokens per k step
+            const u32x4 hB = {hb[2 * u][0], hb[2 * u][1], hb[2 * u + 1][0], hb[2 * u + 1][1]};
+            const u32x4 dzA = {dzb[2 * u][0], dzb[2 * u][1], dzb[2 * u + 1][0], dzb[2 * u + 1][1]};
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) {
+                dw2[dt] = mfma_bf16(tr_frag<LD>(dyimg, 32 * u, dt, lane), hB, dw2[dt]);     // [d 16 dt + 4 q + r][hid]
+                dw1[dt] = mfma_bf16(dzA, tr_frag<LD>(ximg, 32 * u, dt, lane), dw1[dt]);     // [hidden 16 w + 4 q + r][d 16 dt + j]
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        __syncthreads();
+    }
+    float *p1 = a.dw1 + (long long)blockIdx.y * a.dff * D, *p2 = a.dw2 + (long long)blockIdx.y * D * a.dff;
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            p2[(long long)(16 * dt + 4 * q + r) * a.dff + hid] = dw2[dt][r];
+            p1[(long long)(c * kFfnChunk + 16 * w + 4 * q + r) * D + 16 * dt + j] = dw1[dt][r];
+        }
+    db1 += __shfl_xor(db1, 16, 64);
+    db1 += __shfl_xor(db1, 32, 64);
+    if (q == 0) a.db1[(long long)blockIdx.y * a.dff + hid] = db1;
+}
+
 // ------------------------------------------------------------------------------------------- attention
 constexpr int kAttThreads = 256;
 constexpr int kDkPad = 32;              // head dimension padded to one MFMA k step
@@ -976,6 +1342,26 @@ inline int elt_grid(int64_t n, int threads, int cap = 256 * 8) {
     return (int)(b < 1 ? 1 : (b > cap ? cap : b));
 }
 
+int ffn_check(const void *n2, const void *w1, const void *b1, const void *w2, int64_t T, int d, int dff, float p) {
+    if (!n2 || !w1 || !b1 || !w2) return LTR_ERR_NULL;
+    if (T < 0 || (d != 64 && d != 128) || dff < kFfnChunk || dff % kFfnChunk) return LTR_ERR_SHAPE;
+    if (!(p >= 0.f) || p >= 1.f) return LTR_ERR_PARAM;
+    if (((uintptr_t)n2 & 15u) || ((uintptr_t)w1 & 15u) || ((uintptr_t)w2 & 15u) || ((uintptr_t)b1 & 15u)) return LTR_ERR_ALIGN;
+    return 0;
+}
+template <class K>
+int ffn_launch(K kernel, bool (&done)[64], dim3 grid, size_t lds, const FfnArgs &a, hipStream_t stream) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = -1;
+    if (dev < 0 || !done[dev]) {
+        hipError_t e = hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return (int)e;
+        if (dev >= 0) done[dev] = true;
+    }
+    hipLaunchKernelGGL(kernel, grid, dim3(kFfnThreads), lds, stream, a);
+    return status();
+}
+
 }  // namespace
 
 extern "C" {
@@ -1098,6 +1484,50 @@ int ltr_enc_attention_bwd(const uint16_t *qkv, const uint16_t *ctx, const uint16
     if (B == 0) return LTR_OK;
     AttArgs a{qkv, dctx, ctx, mask, dqkv, B, S, h, dk, drop_p, (unsigned long long)seed, stream_id};
     return dispatch_att<true>(a, att_bwd_lds(S), (hipStream_t)stream);
+}
+
+int ltr_enc_ffn_supported(int d, int dff) { return (d == 64 || d == 128) && dff >= kFfnChunk && dff % kFfnChunk == 0; }
+
+int ltr_enc_ffn_fwd(const uint16_t *n2, const uint16_t *w1, const float *b1, const uint16_t *w2, const float *b2, const float *x1,
+                    int64_t T, int d, int dff, float drop_p, uint64_t seed, int stream_hidden, int stream_out, float *x2, void *stream) {
+    if (int rc = ffn_check(n2, w1, b1, w2, T, d, dff, drop_p)) return rc;
+    if (!b2 || !x1 || !x2) return LTR_ERR_NULL;
+    if (T == 0) return LTR_OK;
+    FfnArgs a{n2, w1, w2, nullptr, b1, b2, x1, (long long)T, dff, drop_p, (unsigned long long)seed, stream_hidden, stream_out, x2,
+              nullptr, nullptr, nullptr, 0};
+    const dim3 grid((unsigned)((T + kFfnTok - 1) / kFfnTok));
+    static bool d64[64] = {}, d128[64] = {};
+    if (d == 64) return ffn_launch(ffn_fwd_kernel<64>, d64, grid, 2 * (kFfnChunk * (64 + 8) + 64 * (kFfnChunk + 8)) * sizeof(bf16_t), a, (hipStream_t)stream);
+    return ffn_launch(ffn_fwd_kernel<128>, d128, grid, 2 * (kFfnChunk * (128 + 8) + 128 * (kFfnChunk + 8)) * sizeof(bf16_t), a, (hipStream_t)stream);
+}
+
+int ltr_enc_ffn_bwd_x(const uint16_t *n2, const uint16_t *w1, const float *b1, const uint16_t *w2, const uint16_t *dy, int64_t T, int d,
+                      int dff, float drop_p, uint64_t seed, int stream_hidden, float *dn2, void *stream) {
+    if (int rc = ffn_check(n2, w1, b1, w2, T, d, dff, drop_p)) return rc;
+    if (!dy || !dn2) return LTR_ERR_NULL;
+    if ((uintptr_t)dy & 15u) return LTR_ERR_ALIGN;
+    if (T == 0) return LTR_OK;
+    FfnArgs a{n2, w1, w2, dy, b1, nullptr, nullptr, (long long)T, dff, drop_p, (unsigned long long)seed, stream_hidden, 0, dn2,
+              nullptr, nullptr, nullptr, 0};
+    const dim3 grid((unsigned)((T + kFfnTok - 1) / kFfnTok));
+    static bool d64[64] = {}, d128[64] = {};
+    if (d == 64) return ffn_launch(ffn_bwd_x_kernel<64>, d64, grid, 2 * (kFfnChunk * (64 + 16) + 64 * (kFfnChunk + 16)) * sizeof(bf16_t), a, (hipStream_t)stream);
+    return ffn_launch(ffn_bwd_x_kernel<128>, d128, grid, 2 * (kFfnChunk * (128 + 16) + 128 * (kFfnChunk + 16)) * sizeof(bf16_t), a, (hipStream_t)stream);
+}
+
+int ltr_enc_ffn_bwd_w(const uint16_t *n2, const uint16_t *w1, const float *b1, const uint16_t *w2, const uint16_t *dy, int64_t T, int d,
+                      int dff, float drop_p, uint64_t seed, int stream_hidden, int nsplit, float *dw1_parts, float *dw2_parts,
+                      float *db1_parts, void *stream) {
+    if (int rc = ffn_check(n2, w1, b1, w2, T, d, dff, drop_p)) return rc;
+    if (!dy || !dw1_parts || !dw2_parts || !db1_parts) return LTR_ERR_NULL;
+    if ((uintptr_t)dy & 15u) return LTR_ERR_ALIGN;
+    if (nsplit < 1 || nsplit > 1024) return LTR_ERR_SHAPE;
+    FfnArgs a{n2, w1, w2, dy, b1, nullptr, nullptr, (long long)T, dff, drop_p, (unsigned long long)seed, stream_hidden, 0, nullptr,
+              dw1_parts, dw2_parts, db1_parts, nsplit};
+    const dim3 grid((unsigned)(dff / kFfnChunk), (unsigned)nsplit);
+    static bool d64[64] = {}, d128[64] = {};
+    if (d == 64) return ffn_launch(ffn_bwd_w_kernel<64>, d64, grid, 2 * 2 * 128 * (64 + 16) * sizeof(bf16_t), a, (hipStream_t)stream);
+    return ffn_launch(ffn_bwd_w_kernel<128>, d128, grid, 2 * 2 * 128 * (128 + 16) * sizeof(bf16_t), a, (hipStream_t)stream);
 }
 
 int ltr_enc_score_fwd(const float *x, const float *a, const float *b, const float *w, const float *bias, int64_t T, int d,

@@ -135,6 +135,36 @@ def layernorm_bwd(x, a, dy, T, d, eps, standard, dx):
     return g[:d], g[d:]
 
 
+def fused_ffn_enabled(d, dff):
+    """The fused FFN kernels (no [T, d_ff] tensor in HBM) cover d_model in {64, 128} with d_ff a multiple of 128;
+    LTR_ENC_FUSED_FFN=0 forces the GEMM path (A/B measurements, tests)."""
+    import os
+    return os.environ.get("LTR_ENC_FUSED_FFN", "1") != "0" and bool(lib().ltr_enc_ffn_supported(int(d), int(dff)))
+
+
+def ffn_fwd(n2, w1, b1, w2, b2, x1, T, d, dff, p, seed, s_hidden, s_out):
+    x2 = torch.empty((T, d), dtype=torch.float32, device=n2.device)
+    check(lib().ltr_enc_ffn_fwd(_ptr(n2), _ptr(w1), _ptr(b1), _ptr(w2), _ptr(b2), _ptr(x1), T, d, dff, float(p), int(seed), s_hidden,
+                                s_out, _ptr(x2), _stream()), "ltr_enc_ffn_fwd")
+    return x2
+
+
+def ffn_bwd(n2, w1, b1, w2, dy, T, d, dff, p, seed, s_hidden):
+    """(dn2 [T, d] fp32, dW1 [dff, d], dW2 [d, dff], db1 [dff])."""
+    dev = n2.device
+    dn2 = torch.empty((T, d), dtype=torch.float32, device=dev)
+    check(lib().ltr_enc_ffn_bwd_x(_ptr(n2), _ptr(w1), _ptr(b1), _ptr(w2), _ptr(dy), T, d, dff, float(p), int(seed), s_hidden, _ptr(dn2),
+                                  _stream()), "ltr_enc_ffn_bwd_x")
+    nsplit = max(1, min(256 // (dff // 128), (T + 127) // 128))
+    p1 = torch.empty((nsplit, dff, d), dtype=torch.float32, device=dev)
+    p2 = torch.empty((nsplit, d, dff), dtype=torch.float32, device=dev)
+    pb = torch.empty((nsplit, dff), dtype=torch.float32, device=dev)
+    check(lib().ltr_enc_ffn_bwd_w(_ptr(n2), _ptr(w1), _ptr(b1), _ptr(w2), _ptr(dy), T, d, dff, float(p), int(seed), s_hidden, nsplit,
+                                  _ptr(p1), _ptr(p2), _ptr(pb), _stream()), "ltr_enc_ffn_bwd_w")
+    return (dn2, sum_partials(p1, nsplit, dff * d).view(dff, d), sum_partials(p2, nsplit, d * dff).view(d, dff),
+            sum_partials(pb, nsplit, dff))
+
+
 class EncoderSpec:
     """Static shape of a `make_model` network (what the kernels need besides the parameter tensors)."""
 
@@ -229,6 +259,7 @@ def _run_forward(spec, x, mask, seed, training, params):
         mask_u8 = (mask.to(dev) == 1).to(torch.uint8).contiguous().view(B, S)
         st["mask_u8"] = mask_u8
         h, dk, dff = spec.heads, spec.dk, spec.d_ff
+        st["fused_ffn"] = fused_ffn_enabled(d, dff)
         for l in range(spec.n_layers):
             a1, b1n, Wq, bq, Wk, bk, Wv, bv, Wo, bo, a2, b2n, W1, b1, W2, b2 = (next(it) for _ in range(16))
             wqkv = cast_bf16(torch.cat([Wq, Wk, Wv], 0))
@@ -245,10 +276,14 @@ def _run_forward(spec, x, mask, seed, training, params):
             x1 = torch.empty((T, d), dtype=torch.float32, device=dev)
             gemm(ctxb, wo16, T, d, d, Cf=x1, bias=bo, residual=x0, drop_p=p_enc, seed=seed, drop_stream=stream_attn_out(l))
             n2 = layernorm_fwd(x1, a2, b2n, T, d, LN_EPS, 0)
-            hid = torch.empty((T, dff), dtype=_U16, device=dev)
-            gemm(n2, w116, T, dff, d, Cb=hid, bias=b1, relu=True, drop_p=p_enc, seed=seed, drop_stream=stream_ffn_hidden(l))
-            x2 = torch.empty((T, d), dtype=torch.float32, device=dev)
-            gemm(hid, w216, T, d, dff, Cf=x2, bias=b2, residual=x1, drop_p=p_enc, seed=seed, drop_stream=stream_ffn_out(l))
+            if st["fused_ffn"]:
+                hid = None
+                x2 = ffn_fwd(n2, w116, b1, w216, b2, x1, T, d, dff, p_enc, seed, stream_ffn_hidden(l), stream_ffn_out(l))
+            else:
+                hid = torch.empty((T, dff), dtype=_U16, device=dev)
+                gemm(n2, w116, T, dff, d, Cb=hid, bias=b1, relu=True, drop_p=p_enc, seed=seed, drop_stream=stream_ffn_hidden(l))
+                x2 = torch.empty((T, d), dtype=torch.float32, device=dev)
+                gemm(hid, w216, T, d, dff, Cf=x2, bias=b2, residual=x1, drop_p=p_enc, seed=seed, drop_stream=stream_ffn_out(l))
             st["layers"].append((x0, n1, qkv, ctxb, x1, n2, hid))
             stream_x = x2
     st["xin"], st["prm"], st["final_x"] = xin, prm, stream_x
@@ -312,13 +347,16 @@ class EncoderScores(torch.autograd.Function):
                     x0, n1, qkv, ctxb, x1, n2, hid = st["layers"][l]
                     # FFN sublayer: x2 = x1 + drop(hid W2^T + b2)
                     dy2, gb2 = _drop_cast_colsum(dx, T, d, p_enc, seed, stream_ffn_out(l))
-                    gW2 = _weight_grad(dy2, hid, T, d, dff)
-                    dz1 = torch.empty((T, dff), dtype=_U16, device=dev)
-                    gemm(dy2, w216, T, dff, d, b_kmajor=True, Cb=dz1, gate=hid, gate_scale=1.0 / (1.0 - p_enc))
-                    gb1 = _colsum(dz1, T, dff)
-                    gW1 = _weight_grad(dz1, n2, T, dff, d)
-                    dn2 = torch.empty((T, d), dtype=torch.float32, device=dev)
-                    gemm(dz1, w116, T, d, dff, b_kmajor=True, Cf=dn2)
+                    if st["fused_ffn"]:
+                        dn2, gW1, gW2, gb1 = ffn_bwd(n2, w116, prm[base + 13], w216, dy2, T, d, dff, p_enc, seed, stream_ffn_hidden(l))
+                    else:
+                        gW2 = _weight_grad(dy2, hid, T, d, dff)
+                        dz1 = torch.empty((T, dff), dtype=_U16, device=dev)
+                        gemm(dy2, w216, T, dff, d, b_kmajor=True, Cb=dz1, gate=hid, gate_scale=1.0 / (1.0 - p_enc))
+                        gb1 = _colsum(dz1, T, dff)
+                        gW1 = _weight_grad(dz1, n2, T, dff, d)
+                        dn2 = torch.empty((T, d), dtype=torch.float32, device=dev)
+                        gemm(dz1, w116, T, d, dff, b_kmajor=True, Cf=dn2)
                     ga2, gb2n = layernorm_bwd(x1, a2, dn2, T, d, LN_EPS, 0, dx)
                     # attention sublayer: x1 = x0 + drop(ctx Wo^T + bo)
                     dyo, gbo = _drop_cast_colsum(dx, T, d, p_enc, seed, stream_attn_out(l))

@@ -241,6 +241,36 @@ def test_attention_without_mask_and_all_masked_slate(enc):
     assert err(got[0], want.view(B, S, d)[0]) < 1e-2 and float(got[1].abs().max()) == 0.0
 
 
+# ------------------------------------------------------------------------------------------------- fused FFN
+@pytest.mark.parametrize("T,d,dff,p", [(700, 128, 384, 0.1), (256, 128, 128, 0.0), (1000, 64, 256, 0.2), (130, 64, 128, 0.0),
+                                       (4096, 128, 2048, 0.1)])
+def test_fused_ffn_matches_the_gemm_path(enc, T, d, dff, p):
+    """ltr_enc_ffn_* (hidden activation in registers, recomputed in the backward) vs the same sublayer through
+    ltr_enc_gemm_bf16: identical rounding points, so only the fp32 summation order differs."""
+    torch.manual_seed(T + d + dff)
+    seed, sh, so = 987654321, 10, 11
+    n2, dy = rnd(T, d), rnd(T, d, scale=0.3)
+    w1, w2 = rnd(dff, d, scale=0.15), rnd(d, dff, scale=0.15)
+    b1, b2, x1 = torch.randn(dff, device=DEV) * 0.2, torch.randn(d, device=DEV), torch.randn(T, d, device=DEV)
+    n2b, dyb, w1b, w2b = bits(n2), bits(dy), bits(w1), bits(w2)
+    hid = torch.empty(T, dff, dtype=torch.int16, device=DEV)
+    enc.gemm(n2b, w1b, T, dff, d, Cb=hid, bias=b1, relu=True, drop_p=p, seed=seed, drop_stream=sh)
+    x2 = torch.empty(T, d, device=DEV)
+    enc.gemm(hid, w2b, T, d, dff, Cf=x2, bias=b2, residual=x1, drop_p=p, seed=seed, drop_stream=so)
+    got = enc.ffn_fwd(n2b, w1b, b1, w2b, b2, x1, T, d, dff, p, seed, sh, so)
+    assert err(got, x2) < 2e-5
+    dz1 = torch.empty(T, dff, dtype=torch.int16, device=DEV)
+    enc.gemm(dyb, w2b, T, dff, d, b_kmajor=True, Cb=dz1, gate=hid, gate_scale=1.0 / (1.0 - p))
+    dn2 = torch.empty(T, d, device=DEV)
+    enc.gemm(dz1, w1b, T, d, dff, b_kmajor=True, Cf=dn2)
+    gW2, gW1, gb1 = enc._weight_grad(dyb, hid, T, d, dff), enc._weight_grad(dz1, n2b, T, dff, d), enc._colsum(dz1, T, dff)
+    f_dn2, f_W1, f_W2, f_b1 = enc.ffn_bwd(n2b, w1b, b1, w2b, dyb, T, d, dff, p, seed, sh)
+    # dz is rounded to bf16 from fp32 sums that differ in their last bits between the two paths: a few entries land on
+    # the other side of a rounding boundary (2^-9 relative each)
+    assert err(f_dn2, dn2) < 2e-3
+    assert err(f_W1, gW1) < 1e-3 and err(f_W2, gW2) < 2e-5 and err(f_b1, gb1) < 1e-3
+
+
 # ------------------------------------------------------------------------------------------------- whole network
 def _build(case, g):
     from architeture.multiLayer import make_model

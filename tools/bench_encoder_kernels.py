@@ -70,6 +70,10 @@ def main():
     rec("dW1 = dz1^T n2 (2048 x 128 over T) + reduce", timeit(lambda: E._weight_grad(hid, x, T, dff, d)), 2 * T * dff * d, T * dff * 2 + T * d * 2)
     rec("dWqkv (384 x 128 over T) + reduce", timeit(lambda: E._weight_grad(Cb_q, x, T, 3 * d, d)), 2 * T * 3 * d * d, T * 8 * d)
     rec("dWo (128 x 128 over T) + reduce", timeit(lambda: E._weight_grad(dy, x, T, d, d)), 2 * T * d * d, T * 4 * d)
+    x1 = torch.randn(T, d, device=dev)
+    for p in (0.0, 0.1):
+        rec(f"fused FFN fwd p={p}", timeit(lambda: E.ffn_fwd(x, w1, b1, w2, b2, x1, T, d, dff, p, 1, 2, 3)), 4 * T * dff * d, T * d * 10)
+        rec(f"fused FFN bwd (x + w + reduces) p={p}", timeit(lambda: E.ffn_bwd(x, w1, b1, w2, dy, T, d, dff, p, 1, 2)), 14 * T * dff * d, T * d * 8)
     qkv, ctx, dqkv = bf(T, 3 * d), torch.empty(T, d, dtype=torch.int16, device=dev), torch.empty(T, 3 * d, dtype=torch.int16, device=dev)
     mask = torch.zeros(B, S, dtype=torch.uint8, device=dev)
     att_f = 2 * 2 * B * h * S * S * dk
