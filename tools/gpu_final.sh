@@ -14,6 +14,9 @@ run bench_c1 300 python bench.py --steps 20 --warmup 3 --loss listnet --slate 32
 run bench_l128 300 python bench.py --steps 20 --warmup 3 --loss lambdaLoss --no-cpu-baseline; tail -1 $OUT/${TAG}_bench_l128.log | cut -c1-200
 run bench_triple 300 python bench.py --steps 20 --warmup 3 --net triple --no-cpu-baseline; tail -1 $OUT/${TAG}_bench_triple.log | cut -c1-200
 run bench_losses 300 python tools/bench_losses.py; grep -E "approx|lambda" $OUT/${TAG}_bench_losses.log
+run bench_c5 300 python tools/bench_encoder.py --batch 256 --steps 10 --warmup 3; tail -1 $OUT/${TAG}_bench_c5.log | cut -c1-400
+run bench_c5_kernels 300 python tools/bench_encoder_kernels.py; grep -c "^{" $OUT/${TAG}_bench_c5_kernels.log
+bash tools/gpu_enc_profile.sh ${TAG}_c5 --batch 256 --steps 5 --warmup 2 > $OUT/${TAG}_c5_profile.txt 2>&1; head -12 $OUT/${TAG}_c5_profile.txt | cut -c1-160
 cd /tmp && export TMPDIR=/tmp
 timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $REPO/$OUT/${TAG}_prof -- python3 $REPO/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-extras > $REPO/$OUT/${TAG}_prof.log 2>&1; echo "[prof] exit $?"
 for set in "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_MFMA SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE"; do
