@@ -672,6 +672,82 @@ __device__ __forceinline__ void ffn_stage(bf16_t *img, const bf16_t *__restrict_
     }
 }
 
+// ---- 128 x 128 bf16 tiles as XOR-swizzled 256-byte-row LDS images filled by LDS-DMA (D = 128 path) -----------------
+// off(row, ch) = 256 row + 16 (ch ^ sw(row)), sw(row) = ((row & 3) << 2) | ((row >> 2) & 3): 16-byte chunk ch of row
+// `row`.  One image serves ds_read_b128 row fragments, 8-byte split fragments and ds_read_b64_tr_b16 transposed
+// fragments without padding, so global_load_lds (which can only write 64 lanes x 16 B contiguously) can fill it: the
+// swizzle is applied to the SOURCE address each lane fetches.  No registers, asynchronous: issued a whole chunk / tile
+// ahead, waited for (vmcnt) right before the barrier that publishes the buffer.
+typedef __attribute__((address_space(1))) const void *gptr_t;
+typedef __attribute__((address_space(3))) void *lptr_t;
+__device__ __forceinline__ int sw_of(int row) { return ((row & 3) << 2) | ((row >> 2) & 3); }
+__device__ __forceinline__ int sw_off(int row, int ch) { return 256 * row + 16 * (ch ^ sw_of(row)); }     // bytes
+// rows [0, 128) of a [rows][128] bf16 block (global row stride ld elements); rows >= row_lim re-read row row_lim - 1
+// (finite data; their products are masked by the callers).  All 8 waves: wave w fills rows 16 w .. 16 w + 15.  The
+// per-lane byte offsets of the four pieces depend on ld only: computed once (DmaLane), 32 bits each.
+struct DmaLane { unsigned off[4]; };
+__device__ __forceinline__ DmaLane dma_lane(long long ld) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    DmaLane L;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = 16 * w + 4 * i + (lane >> 4);
+        L.off[i] = (unsigned)(row * (int)ld + 8 * ((lane & 15) ^ sw_of(row))) * 2u;
+    }
+    return L;
+}
+__device__ __forceinline__ void dma_tile(bf16_t *img, const bf16_t *__restrict__ src, const DmaLane &L, long long ld, long long row_lim) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const char *base = reinterpret_cast<const char *>(src);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        unsigned off = L.off[i];
+        if (row_lim < 128) {            // workgroup-uniform: only a block's last, partial tile
+            const int row = 16 * w + 4 * i + (lane >> 4);
+            if (row >= row_lim) off = (unsigned)(((int)row_lim - 1) * (int)ld + 8 * ((lane & 15) ^ sw_of(row))) * 2u;
+        }
+        __builtin_amdgcn_global_load_lds((gptr_t)(base + off), (lptr_t)(reinterpret_cast<char *>(img) + (16 * w + 4 * i) * 256), 16, 0, 0);
+    }
+}
+__device__ __forceinline__ void dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+// Fragment addressing: sw(row) depends on row & 15 only, and every fragment's row is 16 * tile + (a lane constant), so
+// the swizzle splits into a LANE-CONSTANT byte offset plus (compile-time chunk bits) ^ (lane-constant mask): a handful
+// of address registers per image, tiles and k rows reached through immediate offsets.
+struct SwRow { int base, mhi; };             // ds_read_b128 row fragments: row 16 tile + (lane & 15), chunk 4 k + (lane >> 4)
+struct SwSplit { int lo, hi, mhi; };         // 8-byte split fragments: elements 32 u + 4 q .. and 32 u + 16 + 4 q ..
+struct SwTr { int base, mhi; };              // ds_read_b64_tr_b16 fragments (same contract as tr_frag)
+__device__ __forceinline__ SwRow sw_row_lane(int lane) {
+    const int j = lane & 15, q = lane >> 4, m = sw_of(j) << 4;
+    return SwRow{256 * j + ((16 * q) ^ (m & 0x30)), m & 0xC0};
+}
+__device__ __forceinline__ u32x4 sw_row_frag(const bf16_t *img, const SwRow &s, int tile, int k) {
+    const char *lane_ptr = reinterpret_cast<const char *>(img) + (s.base + ((64 * k) ^ s.mhi));     // 4 distinct values per image
+    return *reinterpret_cast<const u32x4 *>(lane_ptr + 4096 * tile);                                   // immediate offset
+}
+__device__ __forceinline__ SwSplit sw_split_lane(int lane) {
+    const int j = lane & 15, q = lane >> 4, m = sw_of(j) << 4, c = 16 * (q >> 1), h = 8 * (q & 1);
+    return SwSplit{256 * j + (c ^ (m & 0x30)) + h, 256 * j + ((c + 32) ^ (m & 0x30)) + h, m & 0xC0};
+}
+__device__ __forceinline__ u32x4 sw_split_frag(const bf16_t *img, const SwSplit &s, int tile, int u) {
+    const int x = (64 * u) ^ s.mhi;
+    const char *pl = reinterpret_cast<const char *>(img) + (s.lo + x), *ph = reinterpret_cast<const char *>(img) + (s.hi + x);
+    const u32x2 lo = *reinterpret_cast<const u32x2 *>(pl + 4096 * tile), hi = *reinterpret_cast<const u32x2 *>(ph + 4096 * tile);
+    return u32x4{lo[0], lo[1], hi[0], hi[1]};
+}
+__device__ __forceinline__ SwTr sw_tr_lane(int lane) {
+    const int i = lane & 15, g = lane >> 4, rl = 4 * g + (i >> 2), p = i & 3, m = sw_of(rl) << 4;
+    return SwTr{256 * rl + ((16 * (p >> 1)) ^ (m & 0x10)) + 8 * (p & 1), m & 0xE0};
+}
+// rows r0 .. r0 + 31 (r0 a multiple of 16), columns 16 t .. 16 t + 15
+__device__ __forceinline__ u32x4 sw_tr_frag(const bf16_t *img, const SwTr &s, int r0, int t) {
+    typedef __attribute__((address_space(3))) s16x4 *lp4;
+    const char *lane_ptr = reinterpret_cast<const char *>(img) + (s.base + ((32 * t) ^ s.mhi));    // 8 distinct values per image
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp4)(lane_ptr + 256 * r0));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp4)(lane_ptr + 256 * r0 + 16 * 256));      // row + 16: same swizzle
+    const u32x2 l2 = __builtin_bit_cast(u32x2, lo), h2 = __builtin_bit_cast(u32x2, hi);
+    return u32x4{l2[0], l2[1], h2[0], h2[1]};
+}
+
 // B-operand fragments of a token tile straight from global: token = lane & 15, k-step k of 32 features.
 //   SPLIT = false: features 32 k + 8 g .. + 7 (pairs with ds_read_b128 row fragments)
 //   SPLIT = true : features 32 k + 4 g .. + 3 and 32 k + 16 + 4 g .. + 3 (pairs with transposed reads)
@@ -692,7 +768,8 @@ __device__ __forceinline__ void ffn_z(const bf16_t *w1img, int ht, const u32x4 (
     z[0] = z[1] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int k = 0; k < D / 32; ++k) {
-        const u32x4 a = *reinterpret_cast<const u32x4 *>(w1img + (16 * ht + (lane & 15)) * LD + 32 * k + 8 * (lane >> 4));
+        const u32x4 a = D == 128 ? sw_row_frag(w1img, sw_row_lane(lane), ht, k)
+                                 : *reinterpret_cast<const u32x4 *>(w1img + (16 * ht + (lane & 15)) * LD + 32 * k + 8 * (lane >> 4));
         z[0] = mfma_bf16(a, xf[0][k], z[0]);
         z[1] = mfma_bf16(a, xf[1][k], z[1]);
     }
@@ -701,7 +778,8 @@ __device__ __forceinline__ void ffn_z(const bf16_t *w1img, int ht, const u32x4 (
 template <int D>
 __global__ void __launch_bounds__(kFfnThreads) ffn_fwd_kernel(FfnArgs a) {
     extern __shared__ __attribute__((aligned(16))) bf16_t smem[];
-    constexpr int DK = D / 32, DT = D / 16, LD1 = D + 8, LD2 = kFfnChunk + 8;
+    constexpr int DK = D / 32, DT = D / 16, LD1 = D == 128 ? 128 : D + 8, LD2 = D == 128 ? 128 : kFfnChunk + 8;
+    constexpr bool DMA = D == 128;        // swizzled 256-byte-row images filled by LDS-DMA
     constexpr int IMG = kFfnChunk * LD1 + D * LD2;           // W1c [128][LD1] then W2c [D][LD2]
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, j = lane & 15, q = lane >> 4;
     const long long tok0 = (long long)blockIdx.x * kFfnTok + 32 * w;
@@ -717,19 +795,31 @@ __global__ void __launch_bounds__(kFfnThreads) ffn_fwd_kernel(FfnArgs a) {
     for (int dt = 0; dt < DT; ++dt) y[dt][0] = y[dt][1] = f32x4{0.f, 0.f, 0.f, 0.f};
     const int nc = a.dff / kFfnChunk;
     u32x4 r1[kFfnChunk * D / 8 / kFfnThreads], r2[D * kFfnChunk / 8 / kFfnThreads];
-    ffn_load<kFfnChunk, D>(a.w1, D, kFfnChunk, r1);
-    ffn_load<D, kFfnChunk>(a.w2, a.dff, D, r2);
-    ffn_store<kFfnChunk, D, LD1>(smem, r1);
-    ffn_store<D, kFfnChunk, LD2>(smem + kFfnChunk * LD1, r2);
+    const DmaLane L1 = dma_lane(D), L2 = dma_lane(a.dff);
+    if (DMA) {
+        dma_tile(smem, a.w1, L1, D, kFfnChunk);
+        dma_tile(smem + kFfnChunk * LD1, a.w2, L2, a.dff, D);
+        dma_wait();
+    } else {
+        ffn_load<kFfnChunk, D>(a.w1, D, kFfnChunk, r1);
+        ffn_load<D, kFfnChunk>(a.w2, a.dff, D, r2);
+        ffn_store<kFfnChunk, D, LD1>(smem, r1);
+        ffn_store<D, kFfnChunk, LD2>(smem + kFfnChunk * LD1, r2);
+    }
     __syncthreads();
     for (int c = 0; c < nc; ++c) {
         const bf16_t *w1img = smem + (c & 1) * IMG, *w2img = w1img + kFfnChunk * LD1;
         if (c + 1 < nc) {       // next chunk into the other buffer (its last readers passed the barrier below)
             bf16_t *nx = smem + ((c + 1) & 1) * IMG;
-            ffn_load<kFfnChunk, D>(a.w1 + (long long)(c + 1) * kFfnChunk * D, D, kFfnChunk, r1);
-            ffn_load<D, kFfnChunk>(a.w2 + (long long)(c + 1) * kFfnChunk, a.dff, D, r2);
-            ffn_store<kFfnChunk, D, LD1>(nx, r1);
-            ffn_store<D, kFfnChunk, LD2>(nx + kFfnChunk * LD1, r2);
+            if (DMA) {
+                dma_tile(nx, a.w1 + (long long)(c + 1) * kFfnChunk * D, L1, D, kFfnChunk);
+                dma_tile(nx + kFfnChunk * LD1, a.w2 + (long long)(c + 1) * kFfnChunk, L2, a.dff, D);
+            } else {
+                ffn_load<kFfnChunk, D>(a.w1 + (long long)(c + 1) * kFfnChunk * D, D, kFfnChunk, r1);
+                ffn_load<D, kFfnChunk>(a.w2 + (long long)(c + 1) * kFfnChunk, a.dff, D, r2);
+                ffn_store<kFfnChunk, D, LD1>(nx, r1);
+                ffn_store<D, kFfnChunk, LD2>(nx + kFfnChunk * LD1, r2);
+            }
         }
         u32x2 hb[8][2];
 #pragma unroll
@@ -754,14 +844,19 @@ __global__ void __launch_bounds__(kFfnThreads) ffn_fwd_kernel(FfnArgs a) {
             const u32x4 b1v = {hb[2 * u][1][0], hb[2 * u][1][1], hb[2 * u + 1][1][0], hb[2 * u + 1][1][1]};
 #pragma unroll
             for (int dt = 0; dt < DT; ++dt) {
-                const bf16_t *pr = w2img + (16 * dt + j) * LD2 + 32 * u + 4 * q;
-                const u32x2 lo = *reinterpret_cast<const u32x2 *>(pr), hi = *reinterpret_cast<const u32x2 *>(pr + 16);
-                const u32x4 af = {lo[0], lo[1], hi[0], hi[1]};
+                u32x4 af;
+                if (DMA) af = sw_split_frag(w2img, sw_split_lane(lane), dt, u);
+                else {
+                    const bf16_t *pr = w2img + (16 * dt + j) * LD2 + 32 * u + 4 * q;
+                    const u32x2 lo = *reinterpret_cast<const u32x2 *>(pr), hi = *reinterpret_cast<const u32x2 *>(pr + 16);
+                    af = u32x4{lo[0], lo[1], hi[0], hi[1]};
+                }
                 y[dt][0] = mfma_bf16(af, b0, y[dt][0]);
                 y[dt][1] = mfma_bf16(af, b1v, y[dt][1]);
             }
             __builtin_amdgcn_sched_barrier(0);
         }
+        if (DMA) dma_wait();
         __syncthreads();
     }
     // y^T tiles: lane = token, registers = 4 consecutive d
@@ -788,9 +883,10 @@ __global__ void __launch_bounds__(kFfnThreads) ffn_fwd_kernel(FfnArgs a) {
 template <int D>
 __global__ void __launch_bounds__(kFfnThreads) ffn_bwd_x_kernel(FfnArgs a) {
     extern __shared__ __attribute__((aligned(16))) bf16_t smem[];
-    constexpr int DK = D / 32, DT = D / 16, LD1 = D + 16, LD2 = kFfnChunk + 16;   // both images are also read transposed
+    constexpr bool DMA = D == 128;        // swizzled 256-byte-row images filled by LDS-DMA
+    constexpr int DK = D / 32, DT = D / 16, LD1 = DMA ? 128 : D + 16, LD2 = DMA ? 128 : kFfnChunk + 16;   // both images are also read transposed
     constexpr int IMG = kFfnChunk * LD1 + D * LD2;
-    static_assert((LD1 / 2) % 64 == 8 || (LD1 / 2) % 64 == 24 || (LD1 / 2) % 64 == 40 || (LD1 / 2) % 64 == 56, "transposed-read stride");
+    static_assert(DMA || (LD1 / 2) % 64 == 8 || (LD1 / 2) % 64 == 24 || (LD1 / 2) % 64 == 40 || (LD1 / 2) % 64 == 56, "transposed-read stride");
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, j = lane & 15, q = lane >> 4;
     const long long tok0 = (long long)blockIdx.x * kFfnTok + 32 * w;
     const unsigned thr = drop_threshold(a.p);
@@ -807,15 +903,27 @@ __global__ void __launch_bounds__(kFfnThreads) ffn_bwd_x_kernel(FfnArgs a) {
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt) dn[dt][0] = dn[dt][1] = f32x4{0.f, 0.f, 0.f, 0.f};
     const int nc = a.dff / kFfnChunk;
-    ffn_stage<kFfnChunk, D, LD1>(smem, a.w1, D, kFfnChunk);
-    ffn_stage<D, kFfnChunk, LD2>(smem + kFfnChunk * LD1, a.w2, a.dff, D);
+    const DmaLane L1 = dma_lane(D), L2 = dma_lane(a.dff);
+    if (DMA) {
+        dma_tile(smem, a.w1, L1, D, kFfnChunk);
+        dma_tile(smem + kFfnChunk * LD1, a.w2, L2, a.dff, D);
+        dma_wait();
+    } else {
+        ffn_stage<kFfnChunk, D, LD1>(smem, a.w1, D, kFfnChunk);
+        ffn_stage<D, kFfnChunk, LD2>(smem + kFfnChunk * LD1, a.w2, a.dff, D);
+    }
     __syncthreads();
     for (int c = 0; c < nc; ++c) {
         const bf16_t *w1img = smem + (c & 1) * IMG, *w2img = w1img + kFfnChunk * LD1;
         if (c + 1 < nc) {       // next chunk into the other buffer (its last readers passed the barrier below)
             bf16_t *nx = smem + ((c + 1) & 1) * IMG;
-            ffn_stage<kFfnChunk, D, LD1>(nx, a.w1 + (long long)(c + 1) * kFfnChunk * D, D, kFfnChunk);
-            ffn_stage<D, kFfnChunk, LD2>(nx + kFfnChunk * LD1, a.w2 + (long long)(c + 1) * kFfnChunk, a.dff, D);
+            if (DMA) {
+                dma_tile(nx, a.w1 + (long long)(c + 1) * kFfnChunk * D, L1, D, kFfnChunk);
+                dma_tile(nx + kFfnChunk * LD1, a.w2 + (long long)(c + 1) * kFfnChunk, L2, a.dff, D);
+            } else {
+                ffn_stage<kFfnChunk, D, LD1>(nx, a.w1 + (long long)(c + 1) * kFfnChunk * D, D, kFfnChunk);
+                ffn_stage<D, kFfnChunk, LD2>(nx + kFfnChunk * LD1, a.w2 + (long long)(c + 1) * kFfnChunk, a.dff, D);
+            }
         }
         // gate bits: the hidden unit is alive (relu) and kept (dropout)
         unsigned gate[2] = {0u, 0u};          // bit 4 ht + r of word tt
@@ -848,7 +956,7 @@ __global__ void __launch_bounds__(kFfnThreads) ffn_bwd_x_kernel(FfnArgs a) {
             f32x4 dh0 = {0.f, 0.f, 0.f, 0.f}, dh1 = dh0;
 #pragma unroll
             for (int k = 0; k < DK; ++k) {
-                const u32x4 af = tr_frag<LD2>(w2img, 32 * k, ht, lane);
+                const u32x4 af = DMA ? sw_tr_frag(w2img, sw_tr_lane(lane), 32 * k, ht) : tr_frag<LD2>(w2img, 32 * k, ht, lane);
                 dh0 = mfma_bf16(af, dyf[0][k], dh0);
                 dh1 = mfma_bf16(af, dyf[1][k], dh1);
             }
@@ -868,12 +976,13 @@ __global__ void __launch_bounds__(kFfnThreads) ffn_bwd_x_kernel(FfnArgs a) {
             const u32x4 b1v = {dzb[2 * u][1][0], dzb[2 * u][1][1], dzb[2 * u + 1][1][0], dzb[2 * u + 1][1][1]};
 #pragma unroll
             for (int dt = 0; dt < DT; ++dt) {
-                const u32x4 af = tr_frag<LD1>(w1img, 32 * u, dt, lane);
+                const u32x4 af = DMA ? sw_tr_frag(w1img, sw_tr_lane(lane), 32 * u, dt) : tr_frag<LD1>(w1img, 32 * u, dt, lane);
                 dn[dt][0] = mfma_bf16(af, b0, dn[dt][0]);
                 dn[dt][1] = mfma_bf16(af, b1v, dn[dt][1]);
             }
             __builtin_amdgcn_sched_barrier(0);
         }
+        if (DMA) dma_wait();
         __syncthreads();
     }
 #pragma unroll
@@ -889,7 +998,10 @@ __global__ void __launch_bounds__(kFfnThreads) ffn_bwd_x_kernel(FfnArgs a) {
 template <int D>
 __global__ void __launch_bounds__(kFfnThreads) ffn_bwd_w_kernel(FfnArgs a) {
     extern __shared__ __attribute__((aligned(16))) bf16_t smem[];
-    constexpr int DK = D / 32, DT = D / 16, LD = D + 16, TOK = 128, IMG = 2 * TOK * LD;   // n2 tile then dy tile, [token][d]
+    // LDS-DMA + swizzled images measured SLOWER here (456 vs 303 us at T = 65 536: the kernel then needs ~60 registers of
+    // scratch next to its 64 dW accumulators), so the token tiles are staged through registers, piece by piece
+    constexpr bool DMA = false;
+    constexpr int DK = D / 32, DT = D / 16, LD = DMA ? 128 : D + 16, TOK = 128, IMG = 2 * TOK * LD;   // n2 tile then dy tile, [token][d]
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, j = lane & 15, q = lane >> 4;
     const int c = blockIdx.x, hid = c * kFfnChunk + 16 * w + j;          // this lane's hidden unit (as a column)
     const unsigned thr = drop_threshold(a.p);
@@ -913,17 +1025,29 @@ __global__ void __launch_bounds__(kFfnThreads) ffn_bwd_w_kernel(FfnArgs a) {
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt) dw2[dt] = dw1[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
     float db1 = 0.f;
+    const DmaLane L1 = dma_lane(D);
     if (t_beg < t_end) {
-        ffn_stage<TOK, D, LD>(smem, a.n2 + t_beg * TOK * D, D, a.T - t_beg * TOK);
-        ffn_stage<TOK, D, LD>(smem + TOK * LD, a.dy + t_beg * TOK * D, D, a.T - t_beg * TOK);
+        if (DMA) {
+            dma_tile(smem, a.n2 + t_beg * TOK * D, L1, D, a.T - t_beg * TOK);
+            dma_tile(smem + TOK * LD, a.dy + t_beg * TOK * D, L1, D, a.T - t_beg * TOK);
+            dma_wait();
+        } else {
+            ffn_stage<TOK, D, LD>(smem, a.n2 + t_beg * TOK * D, D, a.T - t_beg * TOK);
+            ffn_stage<TOK, D, LD>(smem + TOK * LD, a.dy + t_beg * TOK * D, D, a.T - t_beg * TOK);
+        }
     }
     __syncthreads();
     for (long long t = t_beg; t < t_end; ++t) {
         const bf16_t *ximg = smem + ((t - t_beg) & 1) * IMG, *dyimg = ximg + TOK * LD;
         if (t + 1 < t_end) {
             bf16_t *nx = smem + ((t + 1 - t_beg) & 1) * IMG;
-            ffn_stage<TOK, D, LD>(nx, a.n2 + (t + 1) * TOK * D, D, a.T - (t + 1) * TOK);
-            ffn_stage<TOK, D, LD>(nx + TOK * LD, a.dy + (t + 1) * TOK * D, D, a.T - (t + 1) * TOK);
+            if (DMA) {
+                dma_tile(nx, a.n2 + (t + 1) * TOK * D, L1, D, a.T - (t + 1) * TOK);
+                dma_tile(nx + TOK * LD, a.dy + (t + 1) * TOK * D, L1, D, a.T - (t + 1) * TOK);
+            } else {
+                ffn_stage<TOK, D, LD>(nx, a.n2 + (t + 1) * TOK * D, D, a.T - (t + 1) * TOK);
+                ffn_stage<TOK, D, LD>(nx + TOK * LD, a.dy + (t + 1) * TOK * D, D, a.T - (t + 1) * TOK);
+            }
         }
         u32x2 hb[8], dzb[8];
 #pragma unroll
@@ -931,8 +1055,8 @@ __global__ void __launch_bounds__(kFfnThreads) ffn_bwd_w_kernel(FfnArgs a) {
             f32x4 z = {0.f, 0.f, 0.f, 0.f}, dh = z;        // rows = tokens 16 tt + 4 q + r, column = this lane's hidden unit
 #pragma unroll
             for (int k = 0; k < DK; ++k) {
-                const u32x4 ax = *reinterpret_cast<const u32x4 *>(ximg + (16 * tt + j) * LD + 32 * k + 8 * q);
-                const u32x4 ay = *reinterpret_cast<const u32x4 *>(dyimg + (16 * tt + j) * LD + 32 * k + 8 * q);
+                const u32x4 ax = DMA ? sw_row_frag(ximg, sw_row_lane(lane), tt, k) : *reinterpret_cast<const u32x4 *>(ximg + (16 * tt + j) * LD + 32 * k + 8 * q);
+                const u32x4 ay = DMA ? sw_row_frag(dyimg, sw_row_lane(lane), tt, k) : *reinterpret_cast<const u32x4 *>(dyimg + (16 * tt + j) * LD + 32 * k + 8 * q);
                 z = mfma_bf16(ax, w1f[k], z);
                 dh = mfma_bf16(ay, w2f[k], dh);
             }
@@ -955,11 +1079,12 @@ __global__ void __launch_bounds__(kFfnThreads) ffn_bwd_w_kernel(FfnArgs a) {
             const u32x4 dzA = {dzb[2 * u][0], dzb[2 * u][1], dzb[2 * u + 1][0], dzb[2 * u + 1][1]};
 #pragma unroll
             for (int dt = 0; dt < DT; ++dt) {
-                dw2[dt] = mfma_bf16(tr_frag<LD>(dyimg, 32 * u, dt, lane), hB, dw2[dt]);     // [d 16 dt + 4 q + r][hid]
-                dw1[dt] = mfma_bf16(dzA, tr_frag<LD>(ximg, 32 * u, dt, lane), dw1[dt]);     // [hidden 16 w + 4 q + r][d 16 dt + j]
+                dw2[dt] = mfma_bf16(DMA ? sw_tr_frag(dyimg, sw_tr_lane(lane), 32 * u, dt) : tr_frag<LD>(dyimg, 32 * u, dt, lane), hB, dw2[dt]);     // [d 16 dt + 4 q + r][hid]
+                dw1[dt] = mfma_bf16(dzA, DMA ? sw_tr_frag(ximg, sw_tr_lane(lane), 32 * u, dt) : tr_frag<LD>(ximg, 32 * u, dt, lane), dw1[dt]);     // [hidden 16 w + 4 q + r][d 16 dt + j]
             }
             __builtin_amdgcn_sched_barrier(0);
         }
+        if (DMA) dma_wait();
         __syncthreads();
     }
     float *p1 = a.dw1 + (long long)blockIdx.y * a.dff * D, *p2 = a.dw2 + (long long)blockIdx.y * D * a.dff;
@@ -1498,7 +1623,7 @@ int ltr_enc_ffn_fwd(const uint16_t *n2, const uint16_t *w1, const float *b1, con
     const dim3 grid((unsigned)((T + kFfnTok - 1) / kFfnTok));
     static bool d64[64] = {}, d128[64] = {};
     if (d == 64) return ffn_launch(ffn_fwd_kernel<64>, d64, grid, 2 * (kFfnChunk * (64 + 8) + 64 * (kFfnChunk + 8)) * sizeof(bf16_t), a, (hipStream_t)stream);
-    return ffn_launch(ffn_fwd_kernel<128>, d128, grid, 2 * (kFfnChunk * (128 + 8) + 128 * (kFfnChunk + 8)) * sizeof(bf16_t), a, (hipStream_t)stream);
+    return ffn_launch(ffn_fwd_kernel<128>, d128, grid, 2 * 2 * 128 * 128 * sizeof(bf16_t), a, (hipStream_t)stream);
 }
 
 int ltr_enc_ffn_bwd_x(const uint16_t *n2, const uint16_t *w1, const float *b1, const uint16_t *w2, const uint16_t *dy, int64_t T, int d,
@@ -1512,7 +1637,7 @@ int ltr_enc_ffn_bwd_x(const uint16_t *n2, const uint16_t *w1, const float *b1, c
     const dim3 grid((unsigned)((T + kFfnTok - 1) / kFfnTok));
     static bool d64[64] = {}, d128[64] = {};
     if (d == 64) return ffn_launch(ffn_bwd_x_kernel<64>, d64, grid, 2 * (kFfnChunk * (64 + 16) + 64 * (kFfnChunk + 16)) * sizeof(bf16_t), a, (hipStream_t)stream);
-    return ffn_launch(ffn_bwd_x_kernel<128>, d128, grid, 2 * (kFfnChunk * (128 + 16) + 128 * (kFfnChunk + 16)) * sizeof(bf16_t), a, (hipStream_t)stream);
+    return ffn_launch(ffn_bwd_x_kernel<128>, d128, grid, 2 * 2 * 128 * 128 * sizeof(bf16_t), a, (hipStream_t)stream);
 }
 
 int ltr_enc_ffn_bwd_w(const uint16_t *n2, const uint16_t *w1, const float *b1, const uint16_t *w2, const uint16_t *dy, int64_t T, int d,
