@@ -270,6 +270,69 @@ layernorm_bwd_kernel(const float *__restrict__ x, const float *__restrict__ a, c
     block_cols_out(db, d, red, partials + (long long)blockIdx.x * 2 * d + d);
 }
 
+// LayerNorm backward for d <= 128 (d % 4 == 0): a token is 32 lanes x 4 consecutive features (one 16-byte load per
+// array), a wave works on two tokens at once -- twice the bytes in flight of the general kernel above.
+__global__ void __launch_bounds__(kLnThreads)
+layernorm_bwd_v4_kernel(const float *__restrict__ x, const float *__restrict__ a, const float *__restrict__ dy, long long T, int d,
+                        float eps, int standard, float *__restrict__ dxo, float *__restrict__ partials) {
+    __shared__ float red[8 * 128 * 2];        // [4 waves x 2 token slots][da | db][128]
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, half = lane >> 5, l = lane & 31, f0 = 4 * l;
+    const bool in = f0 < d;
+    f32x4 av = {0.f, 0.f, 0.f, 0.f}, da = av, db = av;
+    if (in) av = *reinterpret_cast<const f32x4 *>(a + f0);
+    for (long long t = ((long long)blockIdx.x * 4 + w) * 2 + half; t < T; t += (long long)gridDim.x * 8) {
+        f32x4 v = {0.f, 0.f, 0.f, 0.f}, g = v;
+        if (in) {
+            v = *reinterpret_cast<const f32x4 *>(x + t * d + f0);
+            g = *reinterpret_cast<const f32x4 *>(dy + t * d + f0);
+        }
+        // statistics over the token's 32 lanes (xor 1..16 stays inside the half wave)
+        float s = (v[0] + v[1]) + (v[2] + v[3]);
+#pragma unroll
+        for (int o = 16; o >= 1; o >>= 1) s += __shfl_xor(s, o, 64);
+        const float mean = s / (float)d;
+        f32x4 c = v - mean;
+        if (!in) c = f32x4{0.f, 0.f, 0.f, 0.f};
+        float q = (c[0] * c[0] + c[1] * c[1]) + (c[2] * c[2] + c[3] * c[3]);
+#pragma unroll
+        for (int o = 16; o >= 1; o >>= 1) q += __shfl_xor(q, o, 64);
+        float sigma, r;
+        if (standard) { sigma = sqrtf(q / (float)d + eps); r = 1.f / sigma; }
+        else { sigma = sqrtf(q / (float)(d - 1)); r = 1.f / (sigma + eps); }
+        da += g * c * r;
+        db += g;
+        g *= av;
+        float sg = (g[0] + g[1]) + (g[2] + g[3]), sgc = (g[0] * c[0] + g[1] * c[1]) + (g[2] * c[2] + g[3] * c[3]);
+#pragma unroll
+        for (int o = 16; o >= 1; o >>= 1) {
+            sg += __shfl_xor(sg, o, 64);
+            sgc += __shfl_xor(sgc, o, 64);
+        }
+        const float mg = sg / (float)d;
+        const float k2 = standard ? r * r * r * sgc / (float)d : (sigma > 0.f ? r * r * sgc / ((float)(d - 1) * sigma) : 0.f);
+        if (in) {
+            f32x4 o4 = *reinterpret_cast<const f32x4 *>(dxo + t * d + f0);
+            o4 += r * (g - mg) - k2 * c;
+            *reinterpret_cast<f32x4 *>(dxo + t * d + f0) = o4;
+        }
+    }
+    // column sums: 8 (wave, token slot) partial rows -> fixed-order sum
+    float *row = red + (2 * w + half) * 256;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        row[f0 + k] = da[k];
+        row[128 + f0 + k] = db[k];
+    }
+    __syncthreads();
+    for (int f = threadIdx.x; f < 2 * d; f += kLnThreads) {
+        const int col = f < d ? f : 128 + (f - d);
+        float sacc = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) sacc += red[k * 256 + col];
+        partials[(long long)blockIdx.x * 2 * d + f] = sacc;
+    }
+}
+
 // scores[t] = w . LN(x[t]) + bias
 __global__ void __launch_bounds__(kLnThreads)
 score_fwd_kernel(const float *__restrict__ x, const float *__restrict__ a, const float *__restrict__ b, const float *__restrict__ wv,
@@ -1548,8 +1611,12 @@ int ltr_enc_layernorm_bwd(const float *x, const float *a, const float *dy, int64
                           float *dx, float *partials, int nblk, void *stream) {
     if (!x || !a || !dy || !dx || !partials) return LTR_ERR_NULL;
     if (T < 0 || d < 2 || d > 64 * kLnMax || nblk < 1 || nblk > 65535) return LTR_ERR_SHAPE;
-    hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(nblk), dim3(kLnThreads), 0, (hipStream_t)stream, x, a, dy, (long long)T, d, eps,
-                       standard, dx, partials);
+    if (d <= 128 && d % 4 == 0 && !(((uintptr_t)x | (uintptr_t)dy | (uintptr_t)dx | (uintptr_t)a) & 15u))
+        hipLaunchKernelGGL(layernorm_bwd_v4_kernel, dim3(nblk), dim3(kLnThreads), 0, (hipStream_t)stream, x, a, dy, (long long)T, d, eps,
+                           standard, dx, partials);
+    else
+        hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(nblk), dim3(kLnThreads), 0, (hipStream_t)stream, x, a, dy, (long long)T, d, eps,
+                           standard, dx, partials);
     return status();
 }
 

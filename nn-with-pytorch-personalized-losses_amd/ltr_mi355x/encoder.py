@@ -127,7 +127,7 @@ def layernorm_fwd(x, a, b, T, d, eps, standard, want_f32=False):
 
 def layernorm_bwd(x, a, dy, T, d, eps, standard, dx):
     """dx += (through the norm); returns (d a, d b)."""
-    nblk = max(1, min(_NBLK, (T + 3) // 4))
+    nblk = max(1, min(4 * _NBLK, (T + 7) // 8))
     parts = torch.empty((nblk, 2 * d), dtype=torch.float32, device=x.device)
     check(lib().ltr_enc_layernorm_bwd(_ptr(x), _ptr(a), _ptr(dy), T, d, float(eps), int(standard), _ptr(dx), _ptr(parts), nblk,
                                       _stream()), "ltr_enc_layernorm_bwd")
@@ -296,6 +296,13 @@ class EncoderScores(torch.autograd.Function):
         if len(params) != spec.n_params():
             raise ValueError(f"expected {spec.n_params()} parameter tensors, got {len(params)}")
         require_device(x, *params)
+        ctx.param_dtypes = [p.dtype for p in params]
+        if x.dim() == 3 and x.shape[0] * x.shape[1] == 0:          # empty batch: nothing to launch, zero gradients
+            if spec.has_encoder and mask is None:
+                raise AttributeError("'NoneType' object has no attribute 'unsqueeze'")
+            ctx.spec, ctx.st = spec, None
+            ctx.shapes = [tuple(p.shape) for p in params]
+            return torch.empty(x.shape[:2], dtype=torch.float32, device=x.device)
         with torch.cuda.device(x.device):
             st = _run_forward(spec, x, mask, seed, training, params)
             B, S, _ = st["dims"]
@@ -308,11 +315,13 @@ class EncoderScores(torch.autograd.Function):
             check(lib().ltr_enc_score_fwd(_ptr(st["final_x"]), _ptr(fa), _ptr(fb), _ptr(ow), _ptr(ob), B * S, spec.d_model, LN_EPS,
                                           1 if spec.has_encoder else 0, _ptr(scores), _stream()), "ltr_enc_score_fwd")
         ctx.spec, ctx.seed, ctx.st = spec, int(seed), st
-        ctx.param_dtypes = [p.dtype for p in params]
         return scores
 
     @staticmethod
     def backward(ctx, dscores):
+        if ctx.st is None:
+            zeros = [torch.zeros(sh, dtype=dt, device=dscores.device) for sh, dt in zip(ctx.shapes, ctx.param_dtypes)]
+            return (None, None, None, None, None, *zeros)
         spec, seed, st = ctx.spec, ctx.seed, ctx.st
         B, S, F = st["dims"]
         T = B * S

@@ -409,6 +409,32 @@ def test_network_api_errors_and_features(enc):
         make_model(dict(sizes=[30], input_norm=False, activation=None, dropout=0.0), None, dict(d_output=1), 16).to(DEV)(x, None, None)
 
 
+def test_network_edge_shapes(enc):
+    """Empty batch, one-document slates, tiny and ragged slate lengths, every mask dtype the callers use."""
+    import ltr_encoder_oracle as EO
+    from architeture.multiLayer import make_model
+    torch.manual_seed(3)
+    fc, tr = dict(sizes=[32], input_norm=False, activation=None, dropout=0.0), dict(N=1, d_ff=64, h=4, dropout=0.0, positional_encoding=None)
+    import copy
+    net = make_model(copy.deepcopy(fc), copy.deepcopy(tr), dict(d_output=1), 16).to(DEV).eval()
+    sd = {k: v.detach().cpu().double() for k, v in net.state_dict().items()}
+    cfg = EO.config_of(dict(fc_model=fc, transformer=tr), 16)
+    out = net(torch.zeros(0, 7, 16, device=DEV), torch.zeros(0, 7, dtype=torch.bool, device=DEV), None)
+    assert out.shape == (0, 7)
+    out.sum().backward()
+    assert all(p.grad is not None and float(p.grad.abs().max()) == 0.0 for p in net.parameters())
+    for B, S in ((3, 1), (2, 2), (1, 7), (5, 31), (2, 257)):
+        x = torch.randn(B, S, 16, device=DEV)
+        m = torch.zeros(B, S, dtype=torch.bool, device=DEV)
+        if S > 2:
+            m[0, S - 1] = True
+        want = EO.encoder_scores(sd, x.cpu().double(), m.cpu(), cfg, bf16=True)
+        for mask in (m, m.to(torch.uint8), m.to(torch.float32), m.to(torch.int64)):
+            got = net(x, mask, None)
+            assert got.shape == (B, S)
+            assert relerr(got.detach().cpu().numpy(), want.numpy()) < 1e-2, (B, S, mask.dtype)
+
+
 def test_network_trains(enc):
     """A few Adam steps on a fixed batch reduce the approxNDCG loss (the whole fwd/bwd chain has the right sign)."""
     from architeture.multiLayer import make_model
