@@ -784,6 +784,24 @@ __device__ __forceinline__ void dma_tile(bf16_t *img, const bf16_t *__restrict__
     }
 }
 __device__ __forceinline__ void dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+// Plain row-major variant (landing buffer [128][128], no swizzle) + the LDS -> LDS copy into a padded [128][LD] image:
+// for the weight-gradient kernel, which has neither the registers for staged loads nor for swizzled addressing.
+__device__ __forceinline__ void dma_tile_linear(bf16_t *landing, const bf16_t *__restrict__ src, long long row_lim) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const char *base = reinterpret_cast<const char *>(src);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = 16 * w + 4 * i + (lane >> 4);
+        const unsigned off = (unsigned)((row < row_lim ? row : (int)row_lim - 1) * 128 + 8 * (lane & 15)) * 2u;
+        __builtin_amdgcn_global_load_lds((gptr_t)(base + off), (lptr_t)(reinterpret_cast<char *>(landing) + (16 * w + 4 * i) * 256), 16, 0, 0);
+    }
+}
+template <int LD>
+__device__ __forceinline__ void lds_copy_tile(bf16_t *img, const bf16_t *landing) {
+#pragma unroll 2
+    for (int p = threadIdx.x; p < 128 * 16; p += kFfnThreads)
+        *reinterpret_cast<u32x4 *>(img + (p >> 4) * LD + 8 * (p & 15)) = *reinterpret_cast<const u32x4 *>(landing + p * 8);
+}
 // Fragment addressing: sw(row) depends on row & 15 only, and every fragment's row is 16 * tile + (a lane constant), so
 // the swizzle splits into a LANE-CONSTANT byte offset plus (compile-time chunk bits) ^ (lane-constant mask): a handful
 // of address registers per image, tiles and k rows reached through immediate offsets.
@@ -1073,9 +1091,12 @@ template <int D>
 __global__ void __launch_bounds__(kFfnThreads) ffn_bwd_w_kernel(FfnArgs a) {
     extern __shared__ __attribute__((aligned(16))) bf16_t smem[];
     // LDS-DMA + swizzled images measured SLOWER here (456 vs 303 us at T = 65 536: the kernel then needs ~60 registers of
-    // scratch next to its 64 dW accumulators), so the token tiles are staged through registers, piece by piece
-    constexpr bool DMA = false;
+    // scratch next to its 64 dW accumulators), and staging through registers exposes 8 load latencies per tile.  So
+    // (D = 128): LDS-DMA the NEXT tile into a plain landing buffer while this one is consumed from the padded images,
+    // then copy LDS -> LDS (LAND).  D = 64 stages through registers, piece by piece.
+    constexpr bool DMA = false, LAND = D == 128;
     constexpr int DK = D / 32, DT = D / 16, LD = DMA ? 128 : D + 16, TOK = 128, IMG = 2 * TOK * LD;   // n2 tile then dy tile, [token][d]
+    bf16_t *landing = smem + IMG;          // LAND: [2][128][128] behind the single image pair
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, j = lane & 15, q = lane >> 4;
     const int c = blockIdx.x, hid = c * kFfnChunk + 16 * w + j;          // this lane's hidden unit (as a column)
     const unsigned thr = drop_threshold(a.p);
@@ -1100,7 +1121,19 @@ __global__ void __launch_bounds__(kFfnThreads) ffn_bwd_w_kernel(FfnArgs a) {
     for (int dt = 0; dt < DT; ++dt) dw2[dt] = dw1[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
     float db1 = 0.f;
     const DmaLane L1 = dma_lane(D);
-    if (t_beg < t_end) {
+    if (LAND && t_beg < t_end) {
+        dma_tile_linear(landing, a.n2 + t_beg * TOK * D, a.T - t_beg * TOK);
+        dma_tile_linear(landing + TOK * 128, a.dy + t_beg * TOK * D, a.T - t_beg * TOK);
+        dma_wait();
+        __syncthreads();
+        lds_copy_tile<LD>(smem, landing);
+        lds_copy_tile<LD>(smem + TOK * LD, landing + TOK * 128);
+        __syncthreads();
+        if (t_beg + 1 < t_end) {
+            dma_tile_linear(landing, a.n2 + (t_beg + 1) * TOK * D, a.T - (t_beg + 1) * TOK);
+            dma_tile_linear(landing + TOK * 128, a.dy + (t_beg + 1) * TOK * D, a.T - (t_beg + 1) * TOK);
+        }
+    } else if (t_beg < t_end) {
         if (DMA) {
             dma_tile(smem, a.n2 + t_beg * TOK * D, L1, D, a.T - t_beg * TOK);
             dma_tile(smem + TOK * LD, a.dy + t_beg * TOK * D, L1, D, a.T - t_beg * TOK);
@@ -1112,8 +1145,8 @@ __global__ void __launch_bounds__(kFfnThreads) ffn_bwd_w_kernel(FfnArgs a) {
     }
     __syncthreads();
     for (long long t = t_beg; t < t_end; ++t) {
-        const bf16_t *ximg = smem + ((t - t_beg) & 1) * IMG, *dyimg = ximg + TOK * LD;
-        if (t + 1 < t_end) {
+        const bf16_t *ximg = smem + (LAND ? 0 : ((t - t_beg) & 1) * IMG), *dyimg = ximg + TOK * LD;
+        if (!LAND && t + 1 < t_end) {
             bf16_t *nx = smem + ((t + 1 - t_beg) & 1) * IMG;
             if (DMA) {
                 dma_tile(nx, a.n2 + (t + 1) * TOK * D, L1, D, a.T - (t + 1) * TOK);
@@ -1158,8 +1191,17 @@ __global__ void __launch_bounds__(kFfnThreads) ffn_bwd_w_kernel(FfnArgs a) {
             }
             __builtin_amdgcn_sched_barrier(0);
         }
-        if (DMA) dma_wait();
+        if (DMA || LAND) dma_wait();
         __syncthreads();
+        if (LAND && t + 1 < t_end) {        // every wave is done with the images; the landing buffer holds tile t + 1
+            lds_copy_tile<LD>(smem, landing);
+            lds_copy_tile<LD>(smem + TOK * LD, landing + TOK * 128);
+            __syncthreads();
+            if (t + 2 < t_end) {
+                dma_tile_linear(landing, a.n2 + (t + 2) * TOK * D, a.T - (t + 2) * TOK);
+                dma_tile_linear(landing + TOK * 128, a.dy + (t + 2) * TOK * D, a.T - (t + 2) * TOK);
+            }
+        }
     }
     float *p1 = a.dw1 + (long long)blockIdx.y * a.dff * D, *p2 = a.dw2 + (long long)blockIdx.y * D * a.dff;
 #pragma unroll
@@ -1730,7 +1772,7 @@ int ltr_enc_ffn_bwd_w(const uint16_t *n2, const uint16_t *w1, const float *b1, c
     const dim3 grid((unsigned)(dff / kFfnChunk), (unsigned)nsplit);
     static bool d64[64] = {}, d128[64] = {};
     if (d == 64) return ffn_launch(ffn_bwd_w_kernel<64>, d64, grid, 2 * 2 * 128 * (64 + 16) * sizeof(bf16_t), a, (hipStream_t)stream);
-    return ffn_launch(ffn_bwd_w_kernel<128>, d128, grid, 2 * 2 * 128 * (128 + 16) * sizeof(bf16_t), a, (hipStream_t)stream);
+    return ffn_launch(ffn_bwd_w_kernel<128>, d128, grid, (2 * 128 * (128 + 16) + 2 * 128 * 128) * sizeof(bf16_t), a, (hipStream_t)stream);
 }
 
 int ltr_enc_score_fwd(const float *x, const float *a, const float *b, const float *w, const float *bias, int64_t T, int d,

@@ -107,3 +107,21 @@ def test_cpu_tensors_are_refused():
     net = make_model(dict(sizes=[16], input_norm=False, activation=None, dropout=0.0), None, dict(d_output=1), 8)
     with pytest.raises(LtrDeviceError):
         net(torch.randn(2, 5, 8), None, None)
+
+
+def test_gemm_descriptor_layout_matches_the_header():
+    """ctypes mirror of `struct ltr_gemm_desc` (include/ltr_encoder.h): same field order, 144 bytes on LP64."""
+    import ctypes
+    import re
+    from conftest import ROOT
+    from ltr_mi355x.encoder import GemmDesc
+    import os
+    hdr = open(os.path.join(ROOT, "include", "ltr_encoder.h")).read()
+    body = hdr[hdr.index("typedef struct ltr_gemm_desc {"):hdr.index("} ltr_gemm_desc;")]
+    names = []
+    for decl in body.split("{", 1)[1].split(";"):
+        m = re.match(r"(?:const\s+)?(?:uint16_t|uint64_t|int64_t|int32_t|float)\s+(.*)", decl.strip())
+        if m:
+            names += [n.strip(" *") for n in m.group(1).split(",")]
+    assert names == [f[0] for f in GemmDesc._fields_], names
+    assert ctypes.sizeof(GemmDesc) == 144
