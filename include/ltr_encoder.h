@@ -119,6 +119,14 @@ int ltr_enc_score_fwd(const float *x, const float *a, const float *b, const floa
 int ltr_enc_score_bwd(const float *x, const float *a, const float *b, const float *w, const float *dscores, int64_t T, int d,
                       float eps, int norm, float *dx, float *partials, int nblk, void *stream);
 
+/* ---- The same tail FUSED with approxNDCGLoss (losses/approxNDCG.py:7-53) and both backwards, one workgroup per slate:
+ * scores and d loss / d scores live in LDS only (BASELINE config 5: "MFMA attention path + LDS loss fused").
+ *   labels [B][S] (pad marks padded documents), slate_loss [B] (caller averages), scores [B][S] optional (NULL),
+ *   dx [B*S][d] = grad_scale * d slate_loss / d x, partials [B][3*d + 8] as ltr_enc_score_bwd (one row per slate). */
+int ltr_enc_tail_approxndcg(const float *x, const float *a, const float *b, const float *w, const float *bias, const float *labels,
+                            int B, int S, int d, float ln_eps, int norm, float alpha, float eps, float pad, float grad_scale,
+                            float *slate_loss, float *scores, float *dx, float *partials, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

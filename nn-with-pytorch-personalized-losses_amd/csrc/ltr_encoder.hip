@@ -15,6 +15,7 @@
 //     per-workgroup partials (no float atomics anywhere).
 #include "../../include/ltr_encoder.h"
 #include "../../include/ltr_mi355x.h"
+#include "ltr_slate_losses.h"
 #include <hip/hip_runtime.h>
 
 namespace {
@@ -416,6 +417,125 @@ score_bwd_kernel(const float *__restrict__ x, const float *__restrict__ a, const
     block_cols_out(db, d, red, out + d);
     block_cols_out(dw, d, red, out + 2 * d);
     block_cols_out(dbias, 1, red, out + 3 * d);
+}
+
+// ------------------------------------------------------------------------------------------- scoring tail + LDS loss
+// Encoder.norm + OutputLayer.w_1 + approxNDCGLoss (losses/approxNDCG.py:7-53) + their backward in ONE kernel, one
+// workgroup per slate: (1) scores of the slate's documents (one wave per document, as score_fwd_kernel) go to LDS,
+// (2) the listwise loss runs on them in LDS (approx_ndcg_slate, the device function of the standalone loss kernel),
+// its d loss / d scores stay in LDS, (3) every document is read once more (L2-hot) for the backward through w_1 and the
+// norm: dx, and this slate's partial sums of d a_2, d b_2, d w, d bias.  scores / dscores never touch HBM (the scores
+// are optionally written for callers that want them).
+__global__ void __launch_bounds__(1024)
+tail_approxndcg_kernel(const float *__restrict__ x, const float *__restrict__ a, const float *__restrict__ b,
+                       const float *__restrict__ wv, const float *__restrict__ bias, const float *__restrict__ labels, int S,
+                       int group, int d, float ln_eps, int norm, float alpha, float eps, float pad, float gscale,
+                       float *__restrict__ slate_loss, float *__restrict__ scores_out, float *__restrict__ dxo,
+                       float *__restrict__ partials) {
+    extern __shared__ __attribute__((aligned(16))) float tsm[];
+    const int s_al = (S + 3) & ~3, nw = group / 64;
+    float *sc = tsm, *yl = sc + s_al, *gn = yl + s_al, *gg = gn + s_al, *uu = gg + s_al, *mk = uu + s_al;
+    float *scratch = mk + s_al;                       // [group + 32] for the slate group
+    float *ds = scratch + group + 32;                 // [s_al] d loss / d score
+    float *red = ds + s_al;                           // [nw][d] cross-wave column sums
+    const ltr::SlateGroup g = ltr::make_group(S, group, scratch);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const long long t0 = (long long)blockIdx.x * S;
+    float aw[kLnMax], bw = 0.f;
+#pragma unroll
+    for (int j = 0; j < kLnMax; ++j) {
+        const int f = lane + 64 * j;
+        const float wj = f < d ? wv[f] : 0.f;
+        aw[j] = norm ? (f < d ? a[f] * wj : 0.f) : wj;
+        bw += (norm && f < d) ? b[f] * wj : 0.f;
+    }
+    bw = wave_sum(bw) + bias[0];
+    for (int i = w; i < S; i += nw) {
+        float v[kLnMax];
+#pragma unroll
+        for (int j = 0; j < kLnMax; ++j) v[j] = (lane + 64 * j < d) ? x[(t0 + i) * d + lane + 64 * j] : 0.f;
+        float sdot = 0.f;
+        if (norm) {
+            const LnStats st = ln_stats(v, d, lane, ln_eps, norm == 2);
+#pragma unroll
+            for (int j = 0; j < kLnMax; ++j) sdot += (lane + 64 * j < d) ? aw[j] * (v[j] - st.mean) * st.r : 0.f;
+        } else {
+#pragma unroll
+            for (int j = 0; j < kLnMax; ++j) sdot += aw[j] * v[j];
+        }
+        sdot = wave_sum(sdot) + bw;
+        if (lane == 0) {
+            sc[i] = sdot;
+            if (scores_out) scores_out[t0 + i] = sdot;
+        }
+    }
+    for (int j = g.t; j < S; j += group) ltr::stage_label(labels[t0 + j], pad, yl[j], gn[j]);
+    __syncthreads();
+    const float loss = ltr::approx_ndcg_slate(g, sc, yl, gn, gg, uu, mk, alpha, eps, gscale, true, [&](int i, float v) { ds[i] = v; });
+    if (threadIdx.x == 0) slate_loss[blockIdx.x] = loss;
+    __syncthreads();
+    float wj[kLnMax], av[kLnMax], bv[kLnMax], da[kLnMax], db[kLnMax], dw[kLnMax];
+    float dbias = 0.f;
+#pragma unroll
+    for (int j = 0; j < kLnMax; ++j) {
+        const int f = lane + 64 * j;
+        wj[j] = f < d ? wv[f] : 0.f;
+        av[j] = (norm && f < d) ? a[f] : 0.f;
+        bv[j] = (norm && f < d) ? b[f] : 0.f;
+        da[j] = db[j] = dw[j] = 0.f;
+    }
+    for (int i = w; i < S; i += nw) {
+        const float g0 = ds[i];
+        float v[kLnMax];
+#pragma unroll
+        for (int j = 0; j < kLnMax; ++j) v[j] = (lane + 64 * j < d) ? x[(t0 + i) * d + lane + 64 * j] : 0.f;
+        dbias += g0;
+        if (norm) {
+            const LnStats st = ln_stats(v, d, lane, ln_eps, norm == 2);
+            float c[kLnMax], gv[kLnMax], dx[kLnMax];
+#pragma unroll
+            for (int j = 0; j < kLnMax; ++j) {
+                c[j] = (lane + 64 * j < d) ? v[j] - st.mean : 0.f;
+                const float xh = c[j] * st.r, dyj = g0 * wj[j];
+                dw[j] += g0 * (av[j] * xh + bv[j]);
+                da[j] += dyj * xh;
+                db[j] += dyj;
+                gv[j] = dyj * av[j];
+            }
+            ln_dx(c, gv, st, d, lane, norm == 2, dx);
+#pragma unroll
+            for (int j = 0; j < kLnMax; ++j)
+                if (lane + 64 * j < d) dxo[(t0 + i) * d + lane + 64 * j] = dx[j];
+        } else {
+#pragma unroll
+            for (int j = 0; j < kLnMax; ++j) {
+                dw[j] += g0 * v[j];
+                if (lane + 64 * j < d) dxo[(t0 + i) * d + lane + 64 * j] = g0 * wj[j];
+            }
+        }
+    }
+    // this slate's column sums: waves added in index order
+    float *out = partials + (long long)blockIdx.x * (3 * d + 8);
+    for (int which = 0; which < 3; ++which) {
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < kLnMax; ++j)
+            if (lane + 64 * j < d) red[w * d + lane + 64 * j] = which == 0 ? da[j] : (which == 1 ? db[j] : dw[j]);
+        __syncthreads();
+        for (int f = threadIdx.x; f < d; f += group) {
+            float sacc = 0.f;
+            for (int k = 0; k < nw; ++k) sacc += red[k * d + f];
+            out[which * d + f] = sacc;
+        }
+    }
+    __syncthreads();
+    if (lane == 0) red[w] = dbias;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float sacc = 0.f;
+        for (int k = 0; k < nw; ++k) sacc += red[k];
+        out[3 * d] = sacc;
+    }
 }
 
 // ------------------------------------------------------------------------------------------- column sums
@@ -1773,6 +1893,29 @@ int ltr_enc_ffn_bwd_w(const uint16_t *n2, const uint16_t *w1, const float *b1, c
     static bool d64[64] = {}, d128[64] = {};
     if (d == 64) return ffn_launch(ffn_bwd_w_kernel<64>, d64, grid, 2 * 2 * 128 * (64 + 16) * sizeof(bf16_t), a, (hipStream_t)stream);
     return ffn_launch(ffn_bwd_w_kernel<128>, d128, grid, (2 * 128 * (128 + 16) + 2 * 128 * 128) * sizeof(bf16_t), a, (hipStream_t)stream);
+}
+
+int ltr_enc_tail_approxndcg(const float *x, const float *a, const float *b, const float *w, const float *bias, const float *labels,
+                            int B, int S, int d, float ln_eps, int norm, float alpha, float eps, float pad, float grad_scale,
+                            float *slate_loss, float *scores, float *dx, float *partials, void *stream) {
+    if (!x || !w || !bias || !labels || !slate_loss || !dx || !partials || (norm && (!a || !b))) return LTR_ERR_NULL;
+    if (B < 0 || S < 1 || S > LTR_MAX_SLATE || d < 2 || d > 64 * kLnMax) return LTR_ERR_SHAPE;
+    if (norm < 0 || norm > 2) return LTR_ERR_PARAM;
+    if (B == 0) return LTR_OK;
+    const int group = ltr::pick_group(S), s_al = (S + 3) & ~3, nw = group / 64;
+    const size_t lds = (size_t)(7 * s_al + group + 32 + (nw * d > nw ? nw * d : nw)) * sizeof(float);
+    if (lds > 160 * 1024) return LTR_ERR_SHAPE;
+    static bool done[64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = -1;
+    if (dev < 0 || !done[dev]) {
+        hipError_t e = hipFuncSetAttribute((const void *)tail_approxndcg_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return (int)e;
+        if (dev >= 0) done[dev] = true;
+    }
+    hipLaunchKernelGGL(tail_approxndcg_kernel, dim3(B), dim3(group), lds, (hipStream_t)stream, x, a, b, w, bias, labels, S, group, d,
+                       ln_eps, norm, alpha, eps, pad, grad_scale, slate_loss, scores, dx, partials);
+    return status();
 }
 
 int ltr_enc_score_fwd(const float *x, const float *a, const float *b, const float *w, const float *bias, int64_t T, int d,

@@ -324,79 +324,131 @@ class EncoderScores(torch.autograd.Function):
             return (None, None, None, None, None, *zeros)
         spec, seed, st = ctx.spec, ctx.seed, ctx.st
         B, S, F = st["dims"]
-        T = B * S
-        p_fc, p_enc = st["p"]
-        prm = st["prm"]
-        fc_w16, enc_w16 = st["fc_w16"], st["enc_w16"]
+        T, d, prm = B * S, spec.d_model, st["prm"]
         dev = dscores.device
-        d = spec.d_model
-        grads = [None] * len(prm)
-        n_fc0 = 2 if spec.input_norm else 0
-        n_fc = n_fc0 + 2 * len(spec.fc_sizes)
         with torch.cuda.device(dev):
             ds = dscores.detach().to(torch.float32).contiguous().view(T)
             # ---- output layer (+ final norm)
-            ow = prm[-2]
             fa, fb = (prm[-4], prm[-3]) if spec.has_encoder else (None, None)
             nblk = max(1, min(_NBLK, (T + 3) // 4))
             dx = torch.empty((T, d), dtype=torch.float32, device=dev)
             parts = torch.empty((nblk, 3 * d + 8), dtype=torch.float32, device=dev)
-            check(lib().ltr_enc_score_bwd(_ptr(st["final_x"]), _ptr(fa), _ptr(fb), _ptr(ow), _ptr(ds), T, d, LN_EPS,
+            check(lib().ltr_enc_score_bwd(_ptr(st["final_x"]), _ptr(fa), _ptr(fb), _ptr(prm[-2]), _ptr(ds), T, d, LN_EPS,
                                           1 if spec.has_encoder else 0, _ptr(dx), _ptr(parts), nblk, _stream()), "ltr_enc_score_bwd")
-            g = sum_partials(parts, nblk, 3 * d + 8)
-            grads[-2] = g[2 * d:3 * d].view(1, d)
-            grads[-1] = g[3 * d:3 * d + 1]
-            if spec.has_encoder:
-                grads[-4], grads[-3] = g[:d], g[d:2 * d]
-                h, dk, dff = spec.heads, spec.dk, spec.d_ff
-                for l in reversed(range(spec.n_layers)):
-                    base = n_fc + 16 * l
-                    a1, _, Wq, _, _, _, _, _, Wo, _, a2, _, W1, _, W2, _ = prm[base:base + 16]
-                    wqkv, wo16, w116, w216 = enc_w16[l]
-                    x0, n1, qkv, ctxb, x1, n2, hid = st["layers"][l]
-                    # FFN sublayer: x2 = x1 + drop(hid W2^T + b2)
-                    dy2, gb2 = _drop_cast_colsum(dx, T, d, p_enc, seed, stream_ffn_out(l))
-                    if st["fused_ffn"]:
-                        dn2, gW1, gW2, gb1 = ffn_bwd(n2, w116, prm[base + 13], w216, dy2, T, d, dff, p_enc, seed, stream_ffn_hidden(l))
-                    else:
-                        gW2 = _weight_grad(dy2, hid, T, d, dff)
-                        dz1 = torch.empty((T, dff), dtype=_U16, device=dev)
-                        gemm(dy2, w216, T, dff, d, b_kmajor=True, Cb=dz1, gate=hid, gate_scale=1.0 / (1.0 - p_enc))
-                        gb1 = _colsum(dz1, T, dff)
-                        gW1 = _weight_grad(dz1, n2, T, dff, d)
-                        dn2 = torch.empty((T, d), dtype=torch.float32, device=dev)
-                        gemm(dz1, w116, T, d, dff, b_kmajor=True, Cf=dn2)
-                    ga2, gb2n = layernorm_bwd(x1, a2, dn2, T, d, LN_EPS, 0, dx)
-                    # attention sublayer: x1 = x0 + drop(ctx Wo^T + bo)
-                    dyo, gbo = _drop_cast_colsum(dx, T, d, p_enc, seed, stream_attn_out(l))
-                    gWo = _weight_grad(dyo, ctxb, T, d, d)
-                    dctx = torch.empty((T, d), dtype=_U16, device=dev)
-                    gemm(dyo, wo16, T, d, d, b_kmajor=True, Cb=dctx)
-                    dqkv = torch.empty((T, 3 * d), dtype=_U16, device=dev)
-                    check(lib().ltr_enc_attention_bwd(_ptr(qkv), _ptr(ctxb), _ptr(dctx), _ptr(st["mask_u8"]), B, S, h, dk, p_enc, int(seed),
-                                                      stream_attn(l), _ptr(dqkv), _stream()), "ltr_enc_attention_bwd")
-                    gbqkv = _colsum(dqkv, T, 3 * d)
-                    gWqkv = _weight_grad(dqkv, n1, T, 3 * d, d)
-                    dn1 = torch.empty((T, d), dtype=torch.float32, device=dev)
-                    gemm(dqkv, wqkv, T, d, 3 * d, b_kmajor=True, Cf=dn1)
-                    ga1, gb1n = layernorm_bwd(x0, a1, dn1, T, d, LN_EPS, 0, dx)
-                    grads[base:base + 16] = [ga1, gb1n, gWqkv[:d], gbqkv[:d], gWqkv[d:2 * d], gbqkv[d:2 * d], gWqkv[2 * d:],
-                                             gbqkv[2 * d:], gWo, gbo, ga2, gb2n, gW1, gb1, gW2, gb2]
-            # ---- FCModel backward
-            sizes = [F] + spec.fc_sizes
-            for i in reversed(range(len(spec.fc_sizes))):
-                n_in, n_out = sizes[i], sizes[i + 1]
-                dy, gb = _drop_cast_colsum(dx, T, n_out, p_fc, seed, stream_fc(i))
-                grads[n_fc0 + 2 * i] = _weight_grad(dy, st["fc_in"][i], T, n_out, n_in)
-                grads[n_fc0 + 2 * i + 1] = gb
-                if i > 0 or spec.input_norm:
-                    dx = torch.empty((T, n_in), dtype=torch.float32, device=dev)
-                    gemm(dy, fc_w16[i], T, n_in, n_out, b_kmajor=True, Cf=dx)
-            if spec.input_norm:
-                scratch = torch.zeros((T, F), dtype=torch.float32, device=dev)
-                grads[0], grads[1] = layernorm_bwd(st["xin"], prm[0], dx, T, F, STD_LN_EPS, 1, scratch)
+            grads = _body_backward(spec, seed, st, dx, sum_partials(parts, nblk, 3 * d + 8))
         out = [g if g is None else g.to(dt).reshape(p.shape) for g, dt, p in zip(grads, ctx.param_dtypes, prm)]
         return (None, None, None, None, None, *out)
+
+
+def _body_backward(spec, seed, st, dx, tail):
+    """Everything below the scoring tail: `dx` = d loss / d (encoder output before the final norm) [T, d], `tail` = the
+    reduced tail partials (d a_2 | d b_2 | d w | d bias).  Returns the gradient list in parameter order."""
+    B, S, F = st["dims"]
+    T = B * S
+    p_fc, p_enc = st["p"]
+    prm = st["prm"]
+    fc_w16, enc_w16 = st["fc_w16"], st["enc_w16"]
+    dev = dx.device
+    d = spec.d_model
+    grads = [None] * len(prm)
+    n_fc0 = 2 if spec.input_norm else 0
+    n_fc = n_fc0 + 2 * len(spec.fc_sizes)
+    g = tail
+    grads[-2] = g[2 * d:3 * d].view(1, d)
+    grads[-1] = g[3 * d:3 * d + 1]
+    if spec.has_encoder:
+        grads[-4], grads[-3] = g[:d], g[d:2 * d]
+        h, dk, dff = spec.heads, spec.dk, spec.d_ff
+        for l in reversed(range(spec.n_layers)):
+            base = n_fc + 16 * l
+            a1, _, Wq, _, _, _, _, _, Wo, _, a2, _, W1, _, W2, _ = prm[base:base + 16]
+            wqkv, wo16, w116, w216 = enc_w16[l]
+            x0, n1, qkv, ctxb, x1, n2, hid = st["layers"][l]
+            # FFN sublayer: x2 = x1 + drop(hid W2^T + b2)
+            dy2, gb2 = _drop_cast_colsum(dx, T, d, p_enc, seed, stream_ffn_out(l))
+            if st["fused_ffn"]:
+                dn2, gW1, gW2, gb1 = ffn_bwd(n2, w116, prm[base + 13], w216, dy2, T, d, dff, p_enc, seed, stream_ffn_hidden(l))
+            else:
+                gW2 = _weight_grad(dy2, hid, T, d, dff)
+                dz1 = torch.empty((T, dff), dtype=_U16, device=dev)
+                gemm(dy2, w216, T, dff, d, b_kmajor=True, Cb=dz1, gate=hid, gate_scale=1.0 / (1.0 - p_enc))
+                gb1 = _colsum(dz1, T, dff)
+                gW1 = _weight_grad(dz1, n2, T, dff, d)
+                dn2 = torch.empty((T, d), dtype=torch.float32, device=dev)
+                gemm(dz1, w116, T, d, dff, b_kmajor=True, Cf=dn2)
+            ga2, gb2n = layernorm_bwd(x1, a2, dn2, T, d, LN_EPS, 0, dx)
+            # attention sublayer: x1 = x0 + drop(ctx Wo^T + bo)
+            dyo, gbo = _drop_cast_colsum(dx, T, d, p_enc, seed, stream_attn_out(l))
+            gWo = _weight_grad(dyo, ctxb, T, d, d)
+            dctx = torch.empty((T, d), dtype=_U16, device=dev)
+            gemm(dyo, wo16, T, d, d, b_kmajor=True, Cb=dctx)
+            dqkv = torch.empty((T, 3 * d), dtype=_U16, device=dev)
+            check(lib().ltr_enc_attention_bwd(_ptr(qkv), _ptr(ctxb), _ptr(dctx), _ptr(st["mask_u8"]), B, S, h, dk, p_enc, int(seed),
+                                              stream_attn(l), _ptr(dqkv), _stream()), "ltr_enc_attention_bwd")
+            gbqkv = _colsum(dqkv, T, 3 * d)
+            gWqkv = _weight_grad(dqkv, n1, T, 3 * d, d)
+            dn1 = torch.empty((T, d), dtype=torch.float32, device=dev)
+            gemm(dqkv, wqkv, T, d, 3 * d, b_kmajor=True, Cf=dn1)
+            ga1, gb1n = layernorm_bwd(x0, a1, dn1, T, d, LN_EPS, 0, dx)
+            grads[base:base + 16] = [ga1, gb1n, gWqkv[:d], gbqkv[:d], gWqkv[d:2 * d], gbqkv[d:2 * d], gWqkv[2 * d:],
+                                     gbqkv[2 * d:], gWo, gbo, ga2, gb2n, gW1, gb1, gW2, gb2]
+    # ---- FCModel backward
+    sizes = [F] + spec.fc_sizes
+    for i in reversed(range(len(spec.fc_sizes))):
+        n_in, n_out = sizes[i], sizes[i + 1]
+        dy, gb = _drop_cast_colsum(dx, T, n_out, p_fc, seed, stream_fc(i))
+        grads[n_fc0 + 2 * i] = _weight_grad(dy, st["fc_in"][i], T, n_out, n_in)
+        grads[n_fc0 + 2 * i + 1] = gb
+        if i > 0 or spec.input_norm:
+            dx = torch.empty((T, n_in), dtype=torch.float32, device=dev)
+            gemm(dy, fc_w16[i], T, n_in, n_out, b_kmajor=True, Cf=dx)
+    if spec.input_norm:
+        scratch = torch.zeros((T, F), dtype=torch.float32, device=dev)
+        grads[0], grads[1] = layernorm_bwd(st["xin"], prm[0], dx, T, F, STD_LN_EPS, 1, scratch)
+    return grads
+
+
+class EncoderApproxNDCG(torch.autograd.Function):
+    """The whole network AND approxNDCGLoss (losses/approxNDCG.py:7-53) as one autograd node: the scoring tail, the
+    listwise loss and their backward run in one kernel per slate with scores / d scores in LDS only
+    (ltr_enc_tail_approxndcg) -- BASELINE config 5's "attention path + LDS loss fused".  Returns the mean slate loss."""
+
+    @staticmethod
+    def forward(ctx, spec, x, mask, y_true, seed, training, eps, pad, alpha, *params):
+        if len(params) != spec.n_params():
+            raise ValueError(f"expected {spec.n_params()} parameter tensors, got {len(params)}")
+        require_device(x, y_true, *params)
+        if x.dim() != 3 or tuple(y_true.shape[:2]) != tuple(x.shape[:2]) or x.shape[0] * x.shape[1] == 0:
+            raise ValueError(f"x [B, S, F] and y_true [B, S] with B, S >= 1 expected, got {tuple(x.shape)} / {tuple(y_true.shape)}")
+        ctx.param_dtypes = [p.dtype for p in params]
+        with torch.cuda.device(x.device):
+            st = _run_forward(spec, x, mask, seed, training, params)
+            B, S, _ = st["dims"]
+            T, d, prm = B * S, spec.d_model, st["prm"]
+            if prm[-2].shape[0] != 1:
+                raise NotImplementedError("OutputLayer with d_output > 1 is not built on the HIP path")
+            fa, fb = (prm[-4], prm[-3]) if spec.has_encoder else (None, None)
+            labels = y_true.detach().to(torch.float32).contiguous().view(B, S)
+            slate_loss = torch.empty(B, dtype=torch.float32, device=x.device)
+            dx = torch.empty((T, d), dtype=torch.float32, device=x.device)
+            parts = torch.empty((B, 3 * d + 8), dtype=torch.float32, device=x.device)
+            check(lib().ltr_enc_tail_approxndcg(_ptr(st["final_x"]), _ptr(fa), _ptr(fb), _ptr(prm[-2]), _ptr(prm[-1]), _ptr(labels), B, S, d,
+                                                LN_EPS, 1 if spec.has_encoder else 0, float(alpha), float(eps), float(pad), 1.0 / B,
+                                                _ptr(slate_loss), None, _ptr(dx), _ptr(parts), _stream()), "ltr_enc_tail_approxndcg")
+            loss = torch.empty((), dtype=torch.float32, device=x.device)
+            check(lib().ltr_reduce_sum_f32(_ptr(slate_loss), B, 1.0 / B, _ptr(loss), _stream()), "ltr_reduce_sum_f32")
+            ctx.tail = sum_partials(parts, B, 3 * d + 8)
+        ctx.spec, ctx.seed, ctx.st, ctx.dx = spec, int(seed), st, dx
+        return loss
+
+    @staticmethod
+    def backward(ctx, go):
+        st = ctx.st
+        with torch.cuda.device(go.device):
+            grads = _body_backward(ctx.spec, ctx.seed, st, ctx.dx, ctx.tail)
+            scale = go.detach().to(torch.float32)
+            out = [None if g is None else (g * scale).to(dt).reshape(p.shape) for g, dt, p in zip(grads, ctx.param_dtypes, st["prm"])]
+        return (None, None, None, None, None, None, None, None, None, *out)
 
 
 def encoder_features(spec, x, mask, seed, training, params):

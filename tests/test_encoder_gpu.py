@@ -409,6 +409,39 @@ def test_network_api_errors_and_features(enc):
         make_model(dict(sizes=[30], input_norm=False, activation=None, dropout=0.0), None, dict(d_output=1), 16).to(DEV)(x, None, None)
 
 
+@pytest.mark.parametrize("with_encoder", [True, False])
+def test_fused_tail_loss_matches_the_two_call_form(enc, with_encoder):
+    """LTRModel.ltr_approx_ndcg_loss (tail + loss + backward in one kernel per slate, scores in LDS) vs
+    approxNDCGLoss(net(x, mask, None), y): same forward tensors, so loss and every gradient agree to fp32 rounding."""
+    from architeture.multiLayer import make_model
+    from losses.approxNDCG import approxNDCGLoss
+    import copy
+    torch.manual_seed(9)
+    fc = dict(sizes=[64], input_norm=False, activation=None, dropout=0.0)
+    tr = dict(N=2, d_ff=128, h=4, dropout=0.1, positional_encoding=None) if with_encoder else None
+    net = make_model(copy.deepcopy(fc), copy.deepcopy(tr), dict(d_output=1), 136).to(DEV).train()
+    for B, S in ((5, 100), (3, 256), (2, 7)):
+        x = torch.randn(B, S, 136, device=DEV)
+        y = torch.randint(0, 5, (B, S), device=DEV).float()
+        mask = torch.zeros(B, S, dtype=torch.bool, device=DEV)
+        mask[0, S - 2:] = True
+        y[mask] = -1
+        net.ltr_seed, net._ltr_calls = 11, 0
+        net.zero_grad()
+        la = approxNDCGLoss(net(x, mask, None), y)
+        la.backward()
+        ga = {k: p.grad.clone() for k, p in net.named_parameters()}
+        net.ltr_seed, net._ltr_calls = 11, 0            # same dropout streams
+        net.zero_grad()
+        lb = net.ltr_approx_ndcg_loss(x, mask, y)
+        (2.0 * lb).backward()                            # grad_output is honoured
+        assert abs(float(la) - float(lb)) <= 1e-5 * abs(float(la))
+        gmax = max(float(v.abs().max()) for v in ga.values())
+        for k, p in net.named_parameters():
+            e = float((0.5 * p.grad - ga[k]).abs().max()) / max(float(ga[k].abs().max()), 1e-3 * gmax)
+            assert e < 2e-4, (B, S, k, e)
+
+
 def test_network_edge_shapes(enc):
     """Empty batch, one-document slates, tiny and ragged slate lengths, every mask dtype the callers use."""
     import ltr_encoder_oracle as EO
