@@ -72,3 +72,49 @@ class QueryShardedTrainer:
             dist.all_reduce(self.local.flat, op=dist.ReduceOp.SUM, group=self.group)
         self.opt.step()
         return self.local.flat[-1]
+
+
+class ModuleShardedTrainer:
+    """Query-sharded data parallelism for scorers whose backward fills `param.grad` (the `make_model` networks of
+    architeture/multiLayer.py): every rank runs forward + loss + backward on its slates, then ONE all-reduce(SUM) of the
+    flattened gradients (+ the loss) and the optimizer step.  `reduction`: "mean" (approxNDCG: each rank's gradient is
+    weighted by B_local / B_global first) or "sum" (ListNet, lambdaLoss with reduction="sum").  Every rank gets its own
+    dropout streams (module.ltr_seed is offset by the rank)."""
+
+    def __init__(self, module, optimizer, reduction="mean", group=None):
+        if reduction not in ("mean", "sum"):
+            raise ValueError("reduction must be 'mean' or 'sum'")
+        self.module, self.opt, self.reduction, self.group = module, optimizer, reduction, group
+        self.rank, self.world_size = world()
+        if hasattr(module, "ltr_seed"):
+            module.ltr_seed = (int(module.ltr_seed) + 0xA24BAED4963EE407 * self.rank) & ((1 << 64) - 1)
+        self.params = [p for p in module.parameters() if p.requires_grad]
+
+    def step(self, loss_closure, b_local, global_batch=None):
+        """loss_closure() -> this rank's loss (0-dim, attached to the graph).  Returns the GLOBAL loss (0-dim)."""
+        self.opt.zero_grad(set_to_none=True)
+        loss = loss_closure()
+        loss.backward()
+        dev = loss.device
+        if self.world_size > 1:
+            if global_batch:
+                gb = int(global_batch)
+            else:
+                t = torch.tensor([int(b_local)], dtype=torch.int64, device=dev)
+                dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+                gb = int(t.item())
+            w = float(b_local) / gb if self.reduction == "mean" else 1.0
+            flat = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1).to(torch.float32) for p in self.params]
+                             + [loss.detach().reshape(1).to(torch.float32)]) * w
+            dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
+            off = 0
+            for p in self.params:
+                g = flat[off:off + p.numel()].view_as(p).to(p.dtype)
+                if p.grad is None:
+                    p.grad = g.clone()
+                else:
+                    p.grad.copy_(g)
+                off += p.numel()
+            loss = flat[-1]
+        self.opt.step()
+        return loss.detach()

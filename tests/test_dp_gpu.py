@@ -162,3 +162,68 @@ def test_bench_self_launches_two_ranks():
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["steps"] == 3 and out["value"] > 0 and out["scaling"] == "weak"
     assert out["config"]["batch_per_gpu"] == 1024
+
+
+# ------------------------------------------------------------------------------------------------- make_model networks
+def _enc_net(dev):
+    sys.path.insert(0, os.path.join(ROOT, "nn-with-pytorch-personalized-losses_amd"))
+    from architeture.multiLayer import make_model
+    torch.manual_seed(77)
+    return make_model(dict(sizes=[64], input_norm=False, activation=None, dropout=0.0),
+                      dict(N=2, d_ff=128, h=4, dropout=0.0, positional_encoding=None), dict(d_output=1), 136).to(dev)
+
+
+def _enc_data():
+    g = torch.Generator().manual_seed(5)
+    X = torch.randn(11, 64, 136, generator=g)                 # 11 slates: ragged shards (6 + 5)
+    y = torch.randint(0, 5, (11, 64), generator=g).float()
+    return X, y, torch.zeros(11, 64, dtype=torch.bool)
+
+
+def _enc_worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dev = torch.device("cuda:0")
+    net = _enc_net(dev)
+    from losses.approxNDCG import approxNDCGLoss
+    from ltr_mi355x.dp import ModuleShardedTrainer, shard_range, sync_parameters
+    sync_parameters(net)
+    tr = ModuleShardedTrainer(net, torch.optim.SGD(net.parameters(), lr=0.05), reduction="mean")
+    X, y, m = _enc_data()
+    lo, hi = shard_range(X.shape[0], rank, world)
+    xs, ys, ms = X[lo:hi].to(dev), y[lo:hi].to(dev), m[lo:hi].to(dev)
+    losses = [float(tr.step(lambda: approxNDCGLoss(net(xs, ms, None), ys), hi - lo)) for _ in range(3)]
+    torch.save({"losses": losses, "params": [p.detach().cpu() for p in net.parameters()]}, os.path.join(out_dir, f"rank{rank}.pt"))
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_make_model_two_ranks_equal_single_process():
+    """Set-transformer scorer under query sharding (ragged shards): three SGD steps on two ranks == full batch on one."""
+    with tempfile.TemporaryDirectory() as d:
+        mp.spawn(_enc_worker, args=(2, _free_port(), d), nprocs=2, join=True)
+        r0 = torch.load(os.path.join(d, "rank0.pt"), weights_only=True)
+        r1 = torch.load(os.path.join(d, "rank1.pt"), weights_only=True)
+    dev = torch.device("cuda:0")
+    net = _enc_net(dev)
+    init = [p.detach().cpu().clone() for p in net.parameters()]
+    from losses.approxNDCG import approxNDCGLoss
+    opt = torch.optim.SGD(net.parameters(), lr=0.05)
+    X, y, m = (t.to(dev) for t in _enc_data())
+    ref = []
+    for _ in range(3):
+        opt.zero_grad()
+        loss = approxNDCGLoss(net(X, m, None), y)
+        loss.backward()
+        opt.step()
+        ref.append(float(loss))
+    assert r0["losses"] == r1["losses"]
+    assert max(abs(a - b) / abs(b) for a, b in zip(r0["losses"], ref)) < 1e-4
+    # The UPDATES are compared (biases start at zero: the updates are lr x gradients).  Not bit-equal to the single-process
+    # run: a rank scales d loss / d scores by 1 / B_local where the full batch uses 1 / B_global, and the bf16 roundings
+    # of the backward see differently scaled values (2^-9 each) -- the bf16 bar of tests/test_encoder_gpu.py applies.
+    upd = [(a - i0, c.detach().cpu() - i0) for a, c, i0 in zip(r0["params"], net.parameters(), init)]
+    top = max(float(u.abs().max()) for _, u in upd)
+    for (ua, uc), a, b in zip(upd, r0["params"], r1["params"]):
+        assert torch.equal(a, b)
+        assert float((ua - uc).abs().max()) / max(float(uc.abs().max()), 0.05 * top) < 5e-2
