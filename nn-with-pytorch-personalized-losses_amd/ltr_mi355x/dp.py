@@ -104,8 +104,9 @@ class ModuleShardedTrainer:
                 dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
                 gb = int(t.item())
             w = float(b_local) / gb if self.reduction == "mean" else 1.0
-            flat = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1).to(torch.float32) for p in self.params]
-                             + [loss.detach().reshape(1).to(torch.float32)]) * w
+            dt = torch.float64 if any(p.dtype == torch.float64 for p in self.params) else torch.float32
+            flat = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1).to(dt) for p in self.params]
+                             + [loss.detach().reshape(1).to(dt)]) * w
             dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
             off = 0
             for p in self.params:

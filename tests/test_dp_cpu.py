@@ -132,3 +132,75 @@ def test_shard_range_partitions_queries():
             assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
             sizes = [hi - lo for lo, hi in spans]
             assert max(sizes) - min(sizes) <= 1
+
+
+# ------------------------------------------------------------------------------------------------- ModuleShardedTrainer
+def _encoder_stand_in(params, X, mask, y):
+    """Per-rank compute of the make_model path, on the CPU: the encoder ORACLE (the HIP path needs a GPU)."""
+    import ltr_encoder_oracle as EO
+    import ltr_oracle as O
+    cfg = dict(n_fc=1, input_norm=False, fc_dropout=0.0, has_encoder=True, n_layers=1, heads=2, enc_dropout=0.0)
+    return O.approx_ndcg(EO.encoder_scores(params, X, mask, cfg), y)
+
+
+def _enc_params():
+    sys.path[:0] = [os.path.join(ROOT, "nn-with-pytorch-personalized-losses_amd")]
+    from architeture.multiLayer import make_model
+    torch.manual_seed(3)
+    net = make_model(dict(sizes=[16], input_norm=False, activation=None, dropout=0.0),
+                     dict(N=1, d_ff=32, h=2, dropout=0.0, positional_encoding=None), dict(d_output=1), 8).double()
+    return net
+
+
+def _enc_data():
+    g = torch.Generator().manual_seed(9)
+    X = torch.randn(7, 10, 8, generator=g, dtype=torch.float64)           # 7 slates: ragged shards (4 + 3)
+    y = torch.randint(0, 5, (7, 10), generator=g).double()
+    return X, y, torch.zeros(7, 10, dtype=torch.bool)
+
+
+def _module_worker(rank, world, port, out_dir):
+    sys.path[:0] = [os.path.join(ROOT, "nn-with-pytorch-personalized-losses_amd"), os.path.join(ROOT, "oracle")]
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from ltr_mi355x.dp import ModuleShardedTrainer, shard_range, sync_parameters
+    net = _enc_params()
+    if rank == 1:
+        with torch.no_grad():
+            for p in net.parameters():
+                p.add_(0.5)
+    sync_parameters(net)
+    seed0 = net.ltr_seed
+    tr = ModuleShardedTrainer(net, torch.optim.SGD(net.parameters(), lr=0.1), reduction="mean")
+    assert (net.ltr_seed != seed0) == (rank != 0)                          # per-rank dropout streams
+    X, y, m = _enc_data()
+    lo, hi = shard_range(X.shape[0], rank, world)
+    sd = dict(net.named_parameters())
+    losses = [float(tr.step(lambda: _encoder_stand_in(sd, X[lo:hi], m[lo:hi], y[lo:hi]), hi - lo)) for _ in range(3)]
+    torch.save({"losses": losses, "params": [p.detach().clone() for p in net.parameters()]}, os.path.join(out_dir, f"rank{rank}.pt"))
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_module_trainer_two_ranks_ragged_shards_equal_full_batch():
+    with tempfile.TemporaryDirectory() as d:
+        mp.spawn(_module_worker, args=(2, _free_port(), d), nprocs=2, join=True)
+        r0 = torch.load(os.path.join(d, "rank0.pt"), weights_only=True)
+        r1 = torch.load(os.path.join(d, "rank1.pt"), weights_only=True)
+    sys.path[:0] = [os.path.join(ROOT, "oracle")]
+    net = _enc_params()
+    opt = torch.optim.SGD(net.parameters(), lr=0.1)
+    X, y, m = _enc_data()
+    sd = dict(net.named_parameters())
+    ref = []
+    for _ in range(3):
+        opt.zero_grad()
+        loss = _encoder_stand_in(sd, X, m, y)
+        loss.backward()
+        opt.step()
+        ref.append(float(loss))
+    assert r0["losses"] == r1["losses"]
+    assert max(abs(a - b) / abs(b) for a, b in zip(r0["losses"], ref)) < 1e-9
+    for a, b, c in zip(r0["params"], r1["params"], net.parameters()):
+        assert torch.equal(a, b)
+        assert float((a - c.detach()).abs().max()) < 1e-9
