@@ -33,6 +33,15 @@ int ltr_enc_attn_dropout_mask(uint64_t seed, int stream_id, int B, int S, int h,
 /* out[i] = sum_z parts[z*n + i], z in [0, nsplit) in that fixed order (fp64 accumulator); accumulate != 0: out += . */
 int ltr_enc_sum_partials(const float *parts, int nsplit, int64_t n, int accumulate, float *out, void *stream);
 
+/* The same for `njobs` independent reductions in as few launches as possible (16 jobs per launch); `jobs` is a HOST array. */
+typedef struct ltr_reduce_job {
+    const float *parts;
+    float *out;
+    int64_t n;
+    int32_t nsplit, reserved;
+} ltr_reduce_job;
+int ltr_enc_sum_partials_batch(const ltr_reduce_job *jobs, int njobs, void *stream);
+
 /* ---- LayerNorm, transformer.py:64-88:  y = a_2 * (x - mean) / (std + eps) + b_2, std UNBIASED (torch.std).
  * standard != 0: nn.LayerNorm (multiLayer.py:27: biased variance, eps inside the root).
  *   x [T][d] fp32; y_bf16 [T][d] (the next GEMM's operand) and/or y_f32 [T][d] (either may be NULL, not both). */

@@ -103,12 +103,11 @@ __global__ void cast_bf16_kernel(const float *__restrict__ src, bf16_t *__restri
 // out[e] = sum_z parts[z][e] in a fixed order: 256 threads = ZL z-lanes x EW outputs (EW = 256 / ZL consecutive e, so
 // loads stay coalesced); z-lane l sums z = l, l + ZL, ... in fp64, the ZL lane sums are then added in lane order.
 template <int ZL>
-__global__ void __launch_bounds__(256) sum_partials_kernel(const float *__restrict__ parts, int nsplit, long long n, int accumulate,
-                                                           float *__restrict__ out) {
+__device__ __forceinline__ void sum_partials_body(const float *__restrict__ parts, int nsplit, long long n, int accumulate,
+                                                  float *__restrict__ out, int block, int nblocks, double *red /* LDS [256] */) {
     constexpr int EW = 256 / ZL;
-    __shared__ double red[256];
     const int el = threadIdx.x % EW, zl = threadIdx.x / EW;
-    for (long long e0 = (long long)blockIdx.x * EW; e0 < n; e0 += (long long)gridDim.x * EW) {
+    for (long long e0 = (long long)block * EW; e0 < n; e0 += (long long)nblocks * EW) {
         const long long e = e0 + el;
         double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
         if (e < n) {
@@ -134,6 +133,37 @@ __global__ void __launch_bounds__(256) sum_partials_kernel(const float *__restri
         }
         if (zl == 0 && e < n) out[e] = (float)(accumulate ? (double)out[e] + s : s);
     }
+}
+// few outputs: spend the threads on the split axis; many outputs: one thread per output
+__host__ __device__ inline int reduce_zl(int nsplit, long long n) { return (n >= 65536 || nsplit < 8) ? 1 : (n >= 4096 ? 4 : 16); }
+__device__ __forceinline__ void sum_partials_any(const float *parts, int nsplit, long long n, int accumulate, float *out, int block,
+                                                 int nblocks, double *red) {
+    switch (reduce_zl(nsplit, n)) {        // workgroup-uniform
+        case 1: sum_partials_body<1>(parts, nsplit, n, accumulate, out, block, nblocks, red); break;
+        case 4: sum_partials_body<4>(parts, nsplit, n, accumulate, out, block, nblocks, red); break;
+        default: sum_partials_body<16>(parts, nsplit, n, accumulate, out, block, nblocks, red); break;
+    }
+}
+__global__ void __launch_bounds__(256) sum_partials_kernel(const float *__restrict__ parts, int nsplit, long long n, int accumulate,
+                                                           float *__restrict__ out) {
+    __shared__ double red[256];
+    sum_partials_any(parts, nsplit, n, accumulate, out, blockIdx.x, gridDim.x, red);
+}
+// up to kReduceJobs independent reductions in one launch (blockIdx.y = job): the backward of one training step ends in
+// ~60 of them, each a few microseconds of work
+constexpr int kReduceJobs = 16;
+struct ReduceJobs {
+    const float *parts[kReduceJobs];
+    float *out[kReduceJobs];
+    long long n[kReduceJobs];
+    int nsplit[kReduceJobs];
+    int blocks[kReduceJobs];
+};
+__global__ void __launch_bounds__(256) sum_partials_batch_kernel(ReduceJobs j) {
+    __shared__ double red[256];
+    const int k = blockIdx.y;
+    if ((int)blockIdx.x >= j.blocks[k]) return;
+    sum_partials_any(j.parts[k], j.nsplit[k], j.n[k], 0, j.out[k], blockIdx.x, j.blocks[k], red);
 }
 
 // ------------------------------------------------------------------------------------------- wave helpers
@@ -1759,15 +1789,36 @@ int ltr_enc_sum_partials(const float *parts, int nsplit, int64_t n, int accumula
     if (!parts || !out) return LTR_ERR_NULL;
     if (nsplit < 1 || n < 0) return LTR_ERR_SHAPE;
     if (n == 0) return LTR_OK;
-    hipStream_t s = (hipStream_t)stream;
-    // few outputs: spend the threads on the split axis; many outputs: one thread per output
-    if (n >= 65536 || nsplit < 8)
-        hipLaunchKernelGGL(sum_partials_kernel<1>, dim3(elt_grid(n, 256)), dim3(256), 0, s, parts, nsplit, (long long)n, accumulate, out);
-    else if (n >= 4096)
-        hipLaunchKernelGGL(sum_partials_kernel<4>, dim3(elt_grid(n, 64)), dim3(256), 0, s, parts, nsplit, (long long)n, accumulate, out);
-    else
-        hipLaunchKernelGGL(sum_partials_kernel<16>, dim3(elt_grid(n, 16)), dim3(256), 0, s, parts, nsplit, (long long)n, accumulate, out);
+    const int ew = 256 / reduce_zl(nsplit, n);
+    hipLaunchKernelGGL(sum_partials_kernel, dim3(elt_grid(n, ew)), dim3(256), 0, (hipStream_t)stream, parts, nsplit, (long long)n,
+                       accumulate, out);
     return status();
+}
+
+int ltr_enc_sum_partials_batch(const ltr_reduce_job *jobs, int njobs, void *stream) {
+    if (!jobs) return LTR_ERR_NULL;
+    if (njobs < 0) return LTR_ERR_SHAPE;
+    for (int j0 = 0; j0 < njobs; j0 += kReduceJobs) {
+        ReduceJobs r{};
+        int cnt = 0, maxb = 1;
+        for (int k = j0; k < njobs && cnt < kReduceJobs; ++k) {
+            const ltr_reduce_job &q = jobs[k];
+            if (!q.parts || !q.out) return LTR_ERR_NULL;
+            if (q.nsplit < 1 || q.n < 0) return LTR_ERR_SHAPE;
+            if (q.n == 0) continue;
+            r.parts[cnt] = q.parts;
+            r.out[cnt] = q.out;
+            r.n[cnt] = q.n;
+            r.nsplit[cnt] = q.nsplit;
+            r.blocks[cnt] = elt_grid(q.n, 256 / reduce_zl(q.nsplit, q.n));
+            maxb = r.blocks[cnt] > maxb ? r.blocks[cnt] : maxb;
+            ++cnt;
+        }
+        if (!cnt) continue;
+        hipLaunchKernelGGL(sum_partials_batch_kernel, dim3(maxb, cnt), dim3(256), 0, (hipStream_t)stream, r);
+        if (int rc = status()) return rc;
+    }
+    return LTR_OK;
 }
 
 int ltr_enc_layernorm_fwd(const float *x, const float *a, const float *b, int64_t T, int d, float eps, int standard,

@@ -47,6 +47,7 @@ _PROTOTYPES = {
     "ltr_enc_dropout_mask": (c_int, [c_uint64, c_int, c_int64, c_float, P, P]),
     "ltr_enc_attn_dropout_mask": (c_int, [c_uint64, c_int, c_int, c_int, c_int, c_float, P, P]),
     "ltr_enc_sum_partials": (c_int, [P, c_int, c_int64, c_int, P, P]),
+    "ltr_enc_sum_partials_batch": (c_int, [P, c_int, P]),
     "ltr_enc_layernorm_fwd": (c_int, [P, P, P, c_int64, c_int, c_float, c_int, P, P, P]),
     "ltr_enc_layernorm_bwd": (c_int, [P, P, P, c_int64, c_int, c_float, c_int, P, P, c_int, P]),
     "ltr_enc_gemm_bf16": (c_int, [P, P]),

@@ -56,7 +56,39 @@ def cast_bf16(src):
     return out
 
 
+class ReduceJob(ctypes.Structure):
+    """struct ltr_reduce_job of include/ltr_encoder.h."""
+    _fields_ = [("parts", ctypes.c_void_p), ("out", ctypes.c_void_p), ("n", ctypes.c_int64), ("nsplit", ctypes.c_int32),
+                ("reserved", ctypes.c_int32)]
+
+
+class deferred_reductions:
+    """Within this context `sum_partials` only RECORDS its job and returns the (not yet written) output tensor; all jobs
+    run at exit through ltr_enc_sum_partials_batch, 16 per launch.  The backward of one step ends in ~60 small
+    reductions whose results nothing reads before the gradients are handed back."""
+    current = None
+
+    def __enter__(self):
+        self.jobs, self.keep = [], []
+        self.prev, deferred_reductions.current = deferred_reductions.current, self
+        return self
+
+    def __exit__(self, exc_type, exc, tb):
+        deferred_reductions.current = self.prev
+        if exc_type is None and self.jobs:
+            arr = (ReduceJob * len(self.jobs))(*self.jobs)
+            check(lib().ltr_enc_sum_partials_batch(arr, len(self.jobs), _stream()), "ltr_enc_sum_partials_batch")
+        self.jobs, self.keep = [], []
+        return False
+
+
 def sum_partials(parts, nsplit, n, out=None, accumulate=False):
+    q = deferred_reductions.current
+    if q is not None and out is None and not accumulate:
+        out = torch.empty(n, dtype=torch.float32, device=parts.device)
+        q.jobs.append(ReduceJob(parts.data_ptr(), out.data_ptr(), n, nsplit, 0))
+        q.keep += [parts, out]
+        return out
     if out is None:
         out = torch.empty(n, dtype=torch.float32, device=parts.device)
     check(lib().ltr_enc_sum_partials(_ptr(parts), nsplit, n, int(accumulate), _ptr(out), _stream()), "ltr_enc_sum_partials")
@@ -335,7 +367,8 @@ class EncoderScores(torch.autograd.Function):
             parts = torch.empty((nblk, 3 * d + 8), dtype=torch.float32, device=dev)
             check(lib().ltr_enc_score_bwd(_ptr(st["final_x"]), _ptr(fa), _ptr(fb), _ptr(prm[-2]), _ptr(ds), T, d, LN_EPS,
                                           1 if spec.has_encoder else 0, _ptr(dx), _ptr(parts), nblk, _stream()), "ltr_enc_score_bwd")
-            grads = _body_backward(spec, seed, st, dx, sum_partials(parts, nblk, 3 * d + 8))
+            with deferred_reductions():
+                grads = _body_backward(spec, seed, st, dx, sum_partials(parts, nblk, 3 * d + 8))
         out = [g if g is None else g.to(dt).reshape(p.shape) for g, dt, p in zip(grads, ctx.param_dtypes, prm)]
         return (None, None, None, None, None, *out)
 
@@ -445,7 +478,8 @@ class EncoderApproxNDCG(torch.autograd.Function):
     def backward(ctx, go):
         st = ctx.st
         with torch.cuda.device(go.device):
-            grads = _body_backward(ctx.spec, ctx.seed, st, ctx.dx, ctx.tail)
+            with deferred_reductions():
+                grads = _body_backward(ctx.spec, ctx.seed, st, ctx.dx, ctx.tail)
             scale = go.detach().to(torch.float32)
             out = [None if g is None else (g * scale).to(dt).reshape(p.shape) for g, dt, p in zip(grads, ctx.param_dtypes, st["prm"])]
         return (None, None, None, None, None, None, None, None, None, *out)
