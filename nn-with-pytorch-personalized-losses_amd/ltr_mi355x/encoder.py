@@ -292,11 +292,18 @@ def _run_forward(spec, x, mask, seed, training, params):
         st["mask_u8"] = mask_u8
         h, dk, dff = spec.heads, spec.dk, spec.d_ff
         st["fused_ffn"] = fused_ffn_enabled(d, dff)
+        # all encoder weights to bf16 in ONE cast: [Wq | Wk | Wv | Wo | W1 | W2] per block, concatenated (every piece is a
+        # multiple of 8 elements, so the views stay 16-byte aligned)
+        n_fc_prm = (2 if spec.input_norm else 0) + 2 * len(spec.fc_sizes)
+        blocks = [prm[n_fc_prm + 16 * l:n_fc_prm + 16 * (l + 1)] for l in range(spec.n_layers)]
+        w16_all = cast_bf16(torch.cat([blk[i].reshape(-1) for blk in blocks for i in (2, 4, 6, 8, 12, 14)]))
+        per = 4 * d * d + 2 * d * dff
         for l in range(spec.n_layers):
             a1, b1n, Wq, bq, Wk, bk, Wv, bv, Wo, bo, a2, b2n, W1, b1, W2, b2 = (next(it) for _ in range(16))
-            wqkv = cast_bf16(torch.cat([Wq, Wk, Wv], 0))
+            w16 = w16_all[l * per:(l + 1) * per]
+            wqkv, wo16 = w16[:3 * d * d].view(3 * d, d), w16[3 * d * d:4 * d * d].view(d, d)
+            w116, w216 = w16[4 * d * d:4 * d * d + d * dff].view(dff, d), w16[4 * d * d + d * dff:].view(d, dff)
             bqkv = torch.cat([bq, bk, bv], 0)
-            wo16, w116, w216 = cast_bf16(Wo), cast_bf16(W1), cast_bf16(W2)
             st["enc_w16"].append((wqkv, wo16, w116, w216))
             x0 = stream_x
             n1 = layernorm_fwd(x0, a1, b1n, T, d, LN_EPS, 0)
