@@ -10,7 +10,6 @@ backward needs, the backward walks the layers in reverse and hands every paramet
 gradient w.r.t. the input features is produced, like the FC scorers of this package).  bf16 operands, fp32
 accumulation / residual stream / statistics / gradients.  Device tensors only; no CPU fallback."""
 import ctypes
-import math
 
 import torch
 
