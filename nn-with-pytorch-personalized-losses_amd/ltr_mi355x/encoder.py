@@ -119,9 +119,11 @@ _NBLK = 512     # workgroups (= partial rows) of the column-sum style reductions
 
 
 def _dw_splits(M, N, K):
+    """Split-K factor of a weight-gradient GEMM: enough (tile, slice) workgroups to fill the chip (~512), at least 256
+    tokens (4 k-steps) per slice."""
     tiles = ((M + 127) // 128) * ((N + 127) // 128)
-    s = max(1, min(32, (512 + tiles - 1) // tiles))
-    return max(1, min(s, (K + 1023) // 1024))
+    s = max(1, min(256, 512 // tiles))
+    return max(1, min(s, (K + 255) // 256))
 
 
 def _weight_grad(dy, x, T, n_out, n_in):
