@@ -75,6 +75,22 @@ __device__ __forceinline__ unsigned drop_keep4(unsigned long long seed, int stre
            ((w1 >> 16) >= thr ? 8u : 0u);
 }
 
+// keep flags of 4 elements in ONE column over 4 consecutive rows (idx0 + r * row_stride, r = 0..3) when adjacent lanes
+// hold adjacent columns (even lane = even idx0, row_stride even): the hash word of a row is shared by the lane pair, so
+// each lane evaluates two rows and takes the other two from its partner with one DPP quad-perm each.  EXEC must be full.
+__device__ __forceinline__ unsigned drop_keep_col4(unsigned long long seed, int stream_id, unsigned long long idx0,
+                                                   unsigned long long row_stride, unsigned thr, int lane) {
+    const int par = lane & 1;
+    const unsigned long long base = (idx0 >> 1) + (unsigned long long)(2 * par) * (row_stride >> 1);   // pair index of row 2 par
+    const unsigned wa = drop_word(seed, stream_id, base), wb = drop_word(seed, stream_id, base + (row_stride >> 1));
+    const unsigned xa = (unsigned)__builtin_amdgcn_update_dpp(0, (int)wa, 0xB1, 0xF, 0xF, false);      // partner (lane ^ 1)
+    const unsigned xb = (unsigned)__builtin_amdgcn_update_dpp(0, (int)wb, 0xB1, 0xF, 0xF, false);
+    const unsigned w0 = par ? xa : wa, w1 = par ? xb : wb, w2 = par ? wa : xa, w3 = par ? wb : xb;
+    const unsigned sh = 16u * (unsigned)par;
+    return (((w0 >> sh) & 0xffffu) >= thr ? 1u : 0u) | (((w1 >> sh) & 0xffffu) >= thr ? 2u : 0u) |
+           (((w2 >> sh) & 0xffffu) >= thr ? 4u : 0u) | (((w3 >> sh) & 0xffffu) >= thr ? 8u : 0u);
+}
+
 __global__ void dropout_mask_kernel(unsigned long long seed, int stream_id, long long n, unsigned thr, uint8_t *out) {
     for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long long)gridDim.x * blockDim.x)
         out[e] = drop_keep(seed, stream_id, (unsigned long long)e, thr) ? 1 : 0;
@@ -1318,10 +1334,12 @@ __global__ void __launch_bounds__(kFfnThreads) ffn_bwd_w_kernel(FfnArgs a) {
                 dh = mfma_bf16(ay, w2f[k], dh);
             }
             f32x4 h, dz;
+            const long long tok0 = t * TOK + 16 * tt + 4 * q;
+            const unsigned keep4 = thr ? drop_keep_col4(a.seed, a.stream_hidden, (unsigned long long)tok0 * a.dff + hid, (unsigned long long)a.dff, thr, lane) : 15u;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const long long tok = t * TOK + 16 * tt + 4 * q + r;
-                const bool keep = thr ? drop_keep(a.seed, a.stream_hidden, (unsigned long long)tok * a.dff + hid, thr) : true;
+                const long long tok = tok0 + r;
+                const bool keep = (keep4 >> r) & 1u;
                 h[r] = keep && tok < a.T ? from_bf16(to_bf16(fmaxf(z[r] + b1v, 0.f) * ks)) : 0.f;
                 dz[r] = h[r] > 0.f ? from_bf16(to_bf16(dh[r] * ks)) : 0.f;
                 db1 += dz[r];
@@ -1660,10 +1678,11 @@ __global__ void __launch_bounds__(kAttThreads) attention_bwd_kernel(AttArgs a) {
                 const f32x4 l4 = *reinterpret_cast<const f32x4 *>(lseS + 16 * qt + 4 * g);
                 const f32x4 d4 = *reinterpret_cast<const f32x4 *>(DS + 16 * qt + 4 * g);
                 f32x4 pd, ds;
+                const unsigned keep4 = thr ? drop_keep_col4(a.seed, a.stream_id, attn_idx(blockIdx.x, Sp, 16 * qt + 4 * g, key), (unsigned long long)Sp, thr, lane) : 15u;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const float p = masked ? 0.f : __builtin_amdgcn_exp2f(s[r] * c2 - l4[r]);
-                    const bool keep = thr ? drop_keep(a.seed, a.stream_id, attn_idx(blockIdx.x, Sp, 16 * qt + 4 * g + r, key), thr) : true;
+                    const bool keep = (keep4 >> r) & 1u;
                     pd[r] = keep ? p * ks : 0.f;
                     ds[r] = p * ((keep ? dpd[r] * ks : 0.f) - d4[r]) * scale;
                 }
