@@ -126,6 +126,19 @@ def test_colsum_and_drop_cast_colsum(enc):
         assert torch.equal(out0.view(torch.bfloat16), dx.to(torch.bfloat16))
 
 
+def test_batched_reductions_match_single_and_fp64(enc):
+    """ltr_enc_sum_partials_batch (16 jobs per launch, deferred by the backward) == ltr_enc_sum_partials == fp64 sum."""
+    torch.manual_seed(13)
+    shapes = [(512, 1), (512, 128), (64, 2048), (7, 4096), (16, 262144), (3, 70000), (256, 16384)] * 3      # 21 jobs: 2 launches
+    parts = [torch.randn(ns, n, device=DEV) for ns, n in shapes]
+    single = [enc.sum_partials(p, p.shape[0], p.shape[1]) for p in parts]
+    with enc.deferred_reductions():
+        batched = [enc.sum_partials(p, p.shape[0], p.shape[1]) for p in parts]
+    for p, a, b in zip(parts, single, batched):
+        assert torch.equal(a, b)
+        assert err(a, p.double().sum(0)) < 1e-6
+
+
 # ------------------------------------------------------------------------------------------------- LayerNorm / scoring tail
 def _ln_ref(x, a, b, eps, standard):
     if standard:
