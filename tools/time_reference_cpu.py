@@ -70,6 +70,33 @@ for label, net, loss, B, S in (("DoubleLayerNet (136-136-136-1, dropout on) + ap
     net.train()
     med, lo, hi = median_ms(net_step(net, loss, B, S), ITERS)
     rows.append((label, B, S, med, lo, hi, ITERS))
+# BASELINE config 5: the reference's make_model network (FC 136->128, 6 encoder blocks, 8 heads, d_ff 2048, dropout 0.1)
+if "--no-config5" not in sys.argv:
+    import attr
+    from architeture.multiLayer import make_model           # noqa: E402  (reference)
+
+    @attr.s(auto_attribs=True)
+    class _Tr:
+        N: int
+        d_ff: int
+        h: int
+        dropout: float
+        positional_encoding: object = None
+
+    enc = make_model(fc_model=dict(sizes=[128], input_norm=False, activation=None, dropout=0.0), transformer=_Tr(6, 2048, 8, 0.1),
+                     post_model=dict(d_output=1, output_activation=None), n_features=136)
+    enc.train()
+    B5, S5 = 8, 256
+    x5, y5, m5 = torch.randn(B5, S5, 136), torch.randint(0, 5, (B5, S5)).float(), torch.zeros(B5, S5, dtype=torch.bool)
+    opt5 = torch.optim.Adam(enc.parameters(), lr=1e-4)
+
+    def step5():
+        opt5.zero_grad()
+        approxNDCGLoss(enc(x5, m5, None), y5).backward()
+        opt5.step()
+    it5 = max(ITERS // 4, 5)
+    med, lo, hi = median_ms(step5, it5)
+    rows.append(("make_model (FC 136-128, 6 blocks, 8 heads, d_ff 2048, dropout 0.1) + approxNDCG + Adam (BASELINE config 5, fp32)", B5, S5, med, lo, hi, it5))
 print(f"threads={torch.get_num_threads()} nproc={os.cpu_count()} torch={torch.__version__} iters>={min(r[6] for r in rows)}")
 print("| workload | B | S | median ms/step | min..max ms | slates/s (median) |")
 print("|---|---|---|---|---|---|")
