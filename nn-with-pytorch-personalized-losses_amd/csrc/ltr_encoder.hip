@@ -248,6 +248,38 @@ layernorm_fwd_kernel(const float *__restrict__ x, const float *__restrict__ a, c
     }
 }
 
+// d <= 128 (d % 4 == 0): 32 lanes x 4 consecutive features per token, two tokens per wave (see layernorm_bwd_v4_kernel)
+__global__ void __launch_bounds__(kLnThreads)
+layernorm_fwd_v4_kernel(const float *__restrict__ x, const float *__restrict__ a, const float *__restrict__ b, long long T, int d,
+                        float eps, int standard, bf16_t *__restrict__ yb, float *__restrict__ yf) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, half = lane >> 5, f0 = 4 * (lane & 31);
+    const bool in = f0 < d;
+    f32x4 av = {0.f, 0.f, 0.f, 0.f}, bv = av;
+    if (in) {
+        av = *reinterpret_cast<const f32x4 *>(a + f0);
+        bv = *reinterpret_cast<const f32x4 *>(b + f0);
+    }
+    for (long long t = ((long long)blockIdx.x * 4 + w) * 2 + half; t < T; t += (long long)gridDim.x * 8) {
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (in) v = *reinterpret_cast<const f32x4 *>(x + t * d + f0);
+        float s = (v[0] + v[1]) + (v[2] + v[3]);
+#pragma unroll
+        for (int o = 16; o >= 1; o >>= 1) s += __shfl_xor(s, o, 64);
+        const float mean = s / (float)d;
+        f32x4 c = v - mean;
+        if (!in) c = f32x4{0.f, 0.f, 0.f, 0.f};
+        float q = (c[0] * c[0] + c[1] * c[1]) + (c[2] * c[2] + c[3] * c[3]);
+#pragma unroll
+        for (int o = 16; o >= 1; o >>= 1) q += __shfl_xor(q, o, 64);
+        const float r = standard ? 1.f / sqrtf(q / (float)d + eps) : 1.f / (sqrtf(q / (float)(d - 1)) + eps);
+        if (in) {
+            const f32x4 y = av * c * r + bv;
+            if (yb) *reinterpret_cast<u32x2 *>(yb + t * d + f0) = u32x2{pack_bf16(y[0], y[1]), pack_bf16(y[2], y[3])};
+            if (yf) *reinterpret_cast<f32x4 *>(yf + t * d + f0) = y;
+        }
+    }
+}
+
 // dx of one token through the norm, given g = dy * a per feature (in v_g) and the centred inputs.
 //   annotated:  dx_j = r (g_j - mean g) - r^2 (sum g c) c_j / ((d-1) sigma)
 //   standard:   dx_j = r (g_j - mean g - xhat_j mean(g xhat))
@@ -1845,8 +1877,12 @@ int ltr_enc_layernorm_fwd(const float *x, const float *a, const float *b, int64_
     if (!x || !a || !b || (!y_bf16 && !y_f32)) return LTR_ERR_NULL;
     if (T < 0 || d < 2 || d > 64 * kLnMax) return LTR_ERR_SHAPE;
     if (T == 0) return LTR_OK;
-    hipLaunchKernelGGL(layernorm_fwd_kernel, dim3(elt_grid(T, 4)), dim3(kLnThreads), 0, (hipStream_t)stream, x, a, b, (long long)T, d,
-                       eps, standard, y_bf16, y_f32);
+    if (d <= 128 && d % 4 == 0 && !(((uintptr_t)x | (uintptr_t)a | (uintptr_t)b | (uintptr_t)y_f32) & 15u) && !((uintptr_t)y_bf16 & 7u))
+        hipLaunchKernelGGL(layernorm_fwd_v4_kernel, dim3(elt_grid(T, 8, 256 * 16)), dim3(kLnThreads), 0, (hipStream_t)stream, x, a, b,
+                           (long long)T, d, eps, standard, y_bf16, y_f32);
+    else
+        hipLaunchKernelGGL(layernorm_fwd_kernel, dim3(elt_grid(T, 4)), dim3(kLnThreads), 0, (hipStream_t)stream, x, a, b, (long long)T, d,
+                           eps, standard, y_bf16, y_f32);
     return status();
 }
 
