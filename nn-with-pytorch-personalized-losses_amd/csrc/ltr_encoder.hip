@@ -616,6 +616,121 @@ tail_approxndcg_kernel(const float *__restrict__ x, const float *__restrict__ a,
     }
 }
 
+// 32 lanes x 4 consecutive features per document, two documents per wave (d <= 128, d % 4 == 0): statistics of one
+// document from its lane's 4 values
+struct TokStats { float mean, r, sigma; };
+__device__ __forceinline__ float half_sum(float v) {
+#pragma unroll
+    for (int o = 16; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ TokStats tok_stats(const f32x4 &v, bool in, int d, float eps, int standard, f32x4 &c) {
+    TokStats st;
+    st.mean = half_sum((v[0] + v[1]) + (v[2] + v[3])) / (float)d;
+    c = v - st.mean;
+    if (!in) c = f32x4{0.f, 0.f, 0.f, 0.f};
+    const float q = half_sum((c[0] * c[0] + c[1] * c[1]) + (c[2] * c[2] + c[3] * c[3]));
+    if (standard) { st.sigma = sqrtf(q / (float)d + eps); st.r = 1.f / st.sigma; }
+    else { st.sigma = sqrtf(q / (float)(d - 1)); st.r = 1.f / (st.sigma + eps); }
+    return st;
+}
+
+__global__ void __launch_bounds__(1024)
+tail_approxndcg_v4_kernel(const float *__restrict__ x, const float *__restrict__ a, const float *__restrict__ b,
+                          const float *__restrict__ wv, const float *__restrict__ bias, const float *__restrict__ labels, int S,
+                          int group, int d, float ln_eps, int norm, float alpha, float eps, float pad, float gscale,
+                          float *__restrict__ slate_loss, float *__restrict__ scores_out, float *__restrict__ dxo,
+                          float *__restrict__ partials) {
+    extern __shared__ __attribute__((aligned(16))) float tsm[];
+    const int s_al = (S + 3) & ~3, nw = group / 64;
+    float *sc = tsm, *yl = sc + s_al, *gn = yl + s_al, *gg = gn + s_al, *uu = gg + s_al, *mk = uu + s_al;
+    float *scratch = mk + s_al, *ds = scratch + group + 32, *red = ds + s_al;       // red: [2 nw][3][128] + [2 nw]
+    const ltr::SlateGroup g = ltr::make_group(S, group, scratch);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, half = lane >> 5, f0 = 4 * (lane & 31);
+    const bool in = f0 < d;
+    const long long t0 = (long long)blockIdx.x * S;
+    f32x4 av = {0.f, 0.f, 0.f, 0.f}, bv = av, wj = av;
+    if (in) {
+        wj = *reinterpret_cast<const f32x4 *>(wv + f0);
+        if (norm) {
+            av = *reinterpret_cast<const f32x4 *>(a + f0);
+            bv = *reinterpret_cast<const f32x4 *>(b + f0);
+        }
+    }
+    const f32x4 aw = norm ? av * wj : wj;
+    const float bw = (norm ? half_sum((bv[0] * wj[0] + bv[1] * wj[1]) + (bv[2] * wj[2] + bv[3] * wj[3])) : 0.f) + bias[0];
+    for (int i = 2 * w + half; i < S; i += 2 * nw) {
+        f32x4 v = {0.f, 0.f, 0.f, 0.f}, c;
+        if (in) v = *reinterpret_cast<const f32x4 *>(x + (t0 + i) * d + f0);
+        float sdot;
+        if (norm) {
+            const TokStats st = tok_stats(v, in, d, ln_eps, norm == 2, c);
+            sdot = ((aw[0] * c[0] + aw[1] * c[1]) + (aw[2] * c[2] + aw[3] * c[3])) * st.r;
+        } else sdot = (aw[0] * v[0] + aw[1] * v[1]) + (aw[2] * v[2] + aw[3] * v[3]);
+        sdot = half_sum(sdot) + bw;
+        if ((lane & 31) == 0) {
+            sc[i] = sdot;
+            if (scores_out) scores_out[t0 + i] = sdot;
+        }
+    }
+    for (int j = g.t; j < S; j += group) ltr::stage_label(labels[t0 + j], pad, yl[j], gn[j]);
+    __syncthreads();
+    const float loss = ltr::approx_ndcg_slate(g, sc, yl, gn, gg, uu, mk, alpha, eps, gscale, true, [&](int i, float v) { ds[i] = v; });
+    if (threadIdx.x == 0) slate_loss[blockIdx.x] = loss;
+    __syncthreads();
+    f32x4 da = {0.f, 0.f, 0.f, 0.f}, db = da, dw = da;
+    float dbias = 0.f;
+    for (int i = 2 * w + half; i < S; i += 2 * nw) {
+        const float g0 = ds[i];
+        f32x4 v = {0.f, 0.f, 0.f, 0.f}, c;
+        if (in) v = *reinterpret_cast<const f32x4 *>(x + (t0 + i) * d + f0);
+        dbias += g0;
+        f32x4 dx;
+        if (norm) {
+            const TokStats st = tok_stats(v, in, d, ln_eps, norm == 2, c);
+            const f32x4 xh = c * st.r, dy = wj * g0;
+            dw += (av * xh + bv) * g0;
+            da += dy * xh;
+            db += dy;
+            const f32x4 gv = dy * av;
+            const float sg = half_sum((gv[0] + gv[1]) + (gv[2] + gv[3]));
+            const float sgc = half_sum((gv[0] * c[0] + gv[1] * c[1]) + (gv[2] * c[2] + gv[3] * c[3]));
+            const float mg = sg / (float)d;
+            const float k2 = norm == 2 ? st.r * st.r * st.r * sgc / (float)d
+                                       : (st.sigma > 0.f ? st.r * st.r * sgc / ((float)(d - 1) * st.sigma) : 0.f);
+            dx = (gv - mg) * st.r - c * k2;
+        } else {
+            dw += v * g0;
+            dx = wj * g0;
+        }
+        if (in) *reinterpret_cast<f32x4 *>(dxo + (t0 + i) * d + f0) = dx;
+    }
+    // this slate's column sums over its 2 nw (wave, half) rows, in index order
+    float *row = red + (2 * w + half) * 384;
+    if (in) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            row[f0 + k] = da[k];
+            row[128 + f0 + k] = db[k];
+            row[256 + f0 + k] = dw[k];
+        }
+    }
+    if ((lane & 31) == 0) red[2 * nw * 384 + 2 * w + half] = dbias;
+    __syncthreads();
+    float *out = partials + (long long)blockIdx.x * (3 * d + 8);
+    for (int f = threadIdx.x; f < 3 * d; f += group) {
+        const int which = f / d, col = f - which * d;
+        float sacc = 0.f;
+        for (int k = 0; k < 2 * nw; ++k) sacc += red[k * 384 + which * 128 + col];
+        out[f] = sacc;
+    }
+    if (threadIdx.x == 0) {
+        float sacc = 0.f;
+        for (int k = 0; k < 2 * nw; ++k) sacc += red[2 * nw * 384 + k];
+        out[3 * d] = sacc;
+    }
+}
+
 // ------------------------------------------------------------------------------------------- column sums
 // 256 threads as (row lanes) x (column chunks of W floats): every thread sums its rows' chunk, the row lanes are then
 // combined through LDS in a fixed order.
@@ -2009,18 +2124,26 @@ int ltr_enc_tail_approxndcg(const float *x, const float *a, const float *b, cons
     if (norm < 0 || norm > 2) return LTR_ERR_PARAM;
     if (B == 0) return LTR_OK;
     const int group = ltr::pick_group(S), s_al = (S + 3) & ~3, nw = group / 64;
-    const size_t lds = (size_t)(7 * s_al + group + 32 + (nw * d > nw ? nw * d : nw)) * sizeof(float);
+    const bool v4 = d <= 128 && d % 4 == 0 && !(((uintptr_t)x | (uintptr_t)w | (uintptr_t)a | (uintptr_t)b | (uintptr_t)dx) & 15u);
+    const size_t red = v4 ? (size_t)2 * nw * 385 : (size_t)(nw * d > nw ? nw * d : nw);
+    const size_t lds = (size_t)(7 * s_al + group + 32 + red) * sizeof(float);
     if (lds > 160 * 1024) return LTR_ERR_SHAPE;
     static bool done[64] = {};
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = -1;
     if (dev < 0 || !done[dev]) {
         hipError_t e = hipFuncSetAttribute((const void *)tail_approxndcg_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute((const void *)tail_approxndcg_v4_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return (int)e;
         if (dev >= 0) done[dev] = true;
     }
-    hipLaunchKernelGGL(tail_approxndcg_kernel, dim3(B), dim3(group), lds, (hipStream_t)stream, x, a, b, w, bias, labels, S, group, d,
-                       ln_eps, norm, alpha, eps, pad, grad_scale, slate_loss, scores, dx, partials);
+    if (v4)
+        hipLaunchKernelGGL(tail_approxndcg_v4_kernel, dim3(B), dim3(group), lds, (hipStream_t)stream, x, a, b, w, bias, labels, S, group,
+                           d, ln_eps, norm, alpha, eps, pad, grad_scale, slate_loss, scores, dx, partials);
+    else
+        hipLaunchKernelGGL(tail_approxndcg_kernel, dim3(B), dim3(group), lds, (hipStream_t)stream, x, a, b, w, bias, labels, S, group, d,
+                           ln_eps, norm, alpha, eps, pad, grad_scale, slate_loss, scores, dx, partials);
     return status();
 }
 

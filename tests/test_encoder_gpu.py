@@ -425,7 +425,8 @@ def test_network_api_errors_and_features(enc):
 @pytest.mark.parametrize("with_encoder", [True, False])
 def test_fused_tail_loss_matches_the_two_call_form(enc, with_encoder):
     """LTRModel.ltr_approx_ndcg_loss (tail + loss + backward in one kernel per slate, scores in LDS) vs
-    approxNDCGLoss(net(x, mask, None), y): same forward tensors, so loss and every gradient agree to fp32 rounding."""
+    approxNDCGLoss(net(x, mask, None), y): same forward tensors, so the loss and the tail's gradients agree to fp32 rounding
+    and everything behind the first bf16 cast of the backward to bf16 rounding."""
     from architeture.multiLayer import make_model
     from losses.approxNDCG import approxNDCGLoss
     import copy
@@ -451,8 +452,12 @@ def test_fused_tail_loss_matches_the_two_call_form(enc, with_encoder):
         assert abs(float(la) - float(lb)) <= 1e-5 * abs(float(la))
         gmax = max(float(v.abs().max()) for v in ga.values())
         for k, p in net.named_parameters():
-            e = float((0.5 * p.grad - ga[k]).abs().max()) / max(float(ga[k].abs().max()), 1e-3 * gmax)
-            assert e < 2e-4, (B, S, k, e)
+            tail = k.startswith("output_layer.") or k.startswith("encoder.norm.")
+            # (the key-projection bias has a zero true gradient -- rounding noise: floor on the scale, as elsewhere)
+            e = float((0.5 * p.grad - ga[k]).abs().max()) / max(float(ga[k].abs().max()), (1e-3 if tail else 0.05) * gmax)
+            # the tail's own parameters: fp32 summation order only.  Everything below it sees d loss / d x through a bf16
+            # rounding (ltr_enc_drop_cast_colsum): the two tails' last-bit differences flip a few roundings (2^-9 each)
+            assert e < (2e-4 if tail else 3e-2), (B, S, k, e)
 
 
 def test_network_edge_shapes(enc):
