@@ -355,11 +355,17 @@ __device__ __forceinline__ void dw_mfma(f32x4 (&acc)[TW], const float (&af)[NR],
 #ifndef LTR_H1_BITS
 #define LTR_H1_BITS 0
 #endif
+#ifndef LTR_STG_SWZ
+#define LTR_STG_SWZ 0            // 1: XOR-swizzled dW staging images (A/B experiment): row r keeps its 4-float pieces at
+#endif                           //    position (4 q) ^ 4 ((r >> 1) & 3) inside each 16-feature tile -> 2-way instead of 8-way
+                                 //    conflicted ds_write_b128; fragment reads use two lane bases (even / odd k steps)
 
 template <int W, int TW, int NR, int NC, int BH, int LD>
-__device__ __forceinline__ void dw_chunk_w(f32x4 (&acc)[TW], const float *a_base, const float *b_base) {
+__device__ __forceinline__ void dw_chunk_w(f32x4 (&acc)[TW], const float *a_base, const float *b_base, const float *a_odd,
+                                           const float *b_odd) {
     constexpr int KS = kChunkDocs / 4;
 #if LTR_DW_PIPE
+    static_assert(!LTR_STG_SWZ, "the pipelined variant reads unswizzled images");
     // Fragments double-buffered and the interleave PINNED (one LDS read per MFMA): the reads of k-step s+1 are in
     // flight under the MFMAs of k-step s.  (Left to itself hipcc sinks the reads next to their use and waits
     // lgkmcnt(0) every 5-6 MFMAs.)
@@ -390,23 +396,26 @@ __device__ __forceinline__ void dw_chunk_w(f32x4 (&acc)[TW], const float *a_base
         // LTR_KROT: the second half of the workgroup walks the k steps half a chunk out of phase with its SIMD partner
         const int s = LTR_KROT ? ((s0 + (W >= kWaves / 2 ? KS / 2 : 0)) % KS) : s0;
         float af[NR], bf[NC];
-        dw_load<W, TW, NR, NC, BH, LD>(af, bf, a_base + s * 4 * LD, b_base + s * 4 * LD);
+        dw_load<W, TW, NR, NC, BH, LD>(af, bf, ((s & 1) ? a_odd : a_base) + s * 4 * LD, ((s & 1) ? b_odd : b_base) + s * 4 * LD);
         dw_mfma<W, TW, NR, NC, BH>(acc, af, bf);
     }
 #endif
 }
 
 template <int TW, int NR, int NC, int BH, int LD>
-__device__ __forceinline__ void dw_chunk(int w, f32x4 (&acc)[TW], const float *a_base, const float *b_base) {
+__device__ __forceinline__ void dw_chunk(int w, f32x4 (&acc)[TW], const float *a_base, const float *b_base, const float *a_odd = nullptr,
+                                         const float *b_odd = nullptr) {
+    if (!a_odd) a_odd = a_base;
+    if (!b_odd) b_odd = b_base;
     switch (w) {   // wave-uniform: one specialised, branch-free body per wave
-        case 0: dw_chunk_w<0, TW, NR, NC, BH, LD>(acc, a_base, b_base); break;
-        case 1: dw_chunk_w<1, TW, NR, NC, BH, LD>(acc, a_base, b_base); break;
-        case 2: dw_chunk_w<2, TW, NR, NC, BH, LD>(acc, a_base, b_base); break;
-        case 3: dw_chunk_w<3, TW, NR, NC, BH, LD>(acc, a_base, b_base); break;
-        case 4: dw_chunk_w<4, TW, NR, NC, BH, LD>(acc, a_base, b_base); break;
-        case 5: dw_chunk_w<5, TW, NR, NC, BH, LD>(acc, a_base, b_base); break;
-        case 6: dw_chunk_w<6, TW, NR, NC, BH, LD>(acc, a_base, b_base); break;
-        default: dw_chunk_w<7, TW, NR, NC, BH, LD>(acc, a_base, b_base); break;
+        case 0: dw_chunk_w<0, TW, NR, NC, BH, LD>(acc, a_base, b_base, a_odd, b_odd); break;
+        case 1: dw_chunk_w<1, TW, NR, NC, BH, LD>(acc, a_base, b_base, a_odd, b_odd); break;
+        case 2: dw_chunk_w<2, TW, NR, NC, BH, LD>(acc, a_base, b_base, a_odd, b_odd); break;
+        case 3: dw_chunk_w<3, TW, NR, NC, BH, LD>(acc, a_base, b_base, a_odd, b_odd); break;
+        case 4: dw_chunk_w<4, TW, NR, NC, BH, LD>(acc, a_base, b_base, a_odd, b_odd); break;
+        case 5: dw_chunk_w<5, TW, NR, NC, BH, LD>(acc, a_base, b_base, a_odd, b_odd); break;
+        case 6: dw_chunk_w<6, TW, NR, NC, BH, LD>(acc, a_base, b_base, a_odd, b_odd); break;
+        default: dw_chunk_w<7, TW, NR, NC, BH, LD>(acc, a_base, b_base, a_odd, b_odd); break;
     }
 }
 
@@ -767,10 +776,10 @@ __global__ void __launch_bounds__(kThreads, 2) slate_pipeline_kernel(const PipeA
             if (chunk == c) {
 #pragma unroll
                 for (int To = 0; To < N::NT2; ++To)
-                    *reinterpret_cast<f32x4 *>(Ds + crow * LD + 16 * To + 4 * q) = h2[To];
+                    *reinterpret_cast<f32x4 *>(Ds + crow * LD + 16 * To + ((4 * q) ^ (LTR_STG_SWZ ? 4 * ((crow >> 1) & 3) : 0))) = h2[To];
 #pragma unroll
                 for (int T = 0; T < N::H1T; ++T)
-                    *reinterpret_cast<f32x4 *>(Hs + crow * LD + 16 * T + 4 * q) = h1[T];
+                    *reinterpret_cast<f32x4 *>(Hs + crow * LD + 16 * T + ((4 * q) ^ (LTR_STG_SWZ ? 4 * ((crow >> 1) & 3) : 0))) = h1[T];
             }
 #ifdef LTR_STAMPS_DW
             if (c == 0) { LTR_STAMP(10) } else { LTR_STAMP(13) }
@@ -780,7 +789,10 @@ __global__ void __launch_bounds__(kThreads, 2) slate_pipeline_kernel(const PipeA
             if (c == 0) { LTR_STAMP(11) } else { LTR_STAMP(14) }
 #endif
             if (!LTR_SKIP(a, 2))
-                dw_chunk<N::TW2, N::NT2, N::H1T, N::BH2, LD>(w, accW2, Ds + q * LD + d, Hs + q * LD + d);
+                dw_chunk<N::TW2, N::NT2, N::H1T, N::BH2, LD>(w, accW2, Ds + q * LD + (d ^ (LTR_STG_SWZ ? 4 * (q >> 1) : 0)),
+                                                             Hs + q * LD + (d ^ (LTR_STG_SWZ ? 4 * (q >> 1) : 0)),
+                                                             Ds + q * LD + (d ^ (LTR_STG_SWZ ? 4 * (2 + (q >> 1)) : 0)),
+                                                             Hs + q * LD + (d ^ (LTR_STG_SWZ ? 4 * (2 + (q >> 1)) : 0)));
 #ifdef LTR_STAMPS_DW
             if (c == 0) { LTR_STAMP(12) }
 #endif
@@ -826,12 +838,14 @@ __global__ void __launch_bounds__(kThreads, 2) slate_pipeline_kernel(const PipeA
             __syncthreads();              // every wave is done reading Ds / Hs (dW2 chunk 1)
 #pragma unroll
             for (int To = 0; To < N::NT1; ++To)
-                *reinterpret_cast<f32x4 *>(Ds + my_row * LD + 16 * To + 4 * q) = dz1[To];
+                *reinterpret_cast<f32x4 *>(Ds + my_row * LD + 16 * To + ((4 * q) ^ (LTR_STG_SWZ ? 4 * ((my_row >> 1) & 3) : 0))) = dz1[To];
             __syncthreads();
             if (!LTR_SKIP(a, 2)) {
 #pragma unroll
                 for (int c = 0; c < 2; ++c)
-                    dw_chunk<N::TW1, N::NT1, N::XT, N::BH1, LD>(w, accW1, Ds + (64 * c + q) * LD + d,
+                    dw_chunk<N::TW1, N::NT1, N::XT, N::BH1, LD>(w, accW1, Ds + (64 * c + q) * LD + (d ^ (LTR_STG_SWZ ? 4 * (q >> 1) : 0)),
+                                                                Xs + (64 * c + q) * LD + d,
+                                                                Ds + (64 * c + q) * LD + (d ^ (LTR_STG_SWZ ? 4 * (2 + (q >> 1)) : 0)),
                                                                 Xs + (64 * c + q) * LD + d);
             }
         } else {
@@ -841,11 +855,14 @@ __global__ void __launch_bounds__(kThreads, 2) slate_pipeline_kernel(const PipeA
                 if (chunk == c) {
 #pragma unroll
                     for (int To = 0; To < N::NT1; ++To)
-                        *reinterpret_cast<f32x4 *>(Ds + crow * LD + 16 * To + 4 * q) = dz1[To];
+                        *reinterpret_cast<f32x4 *>(Ds + crow * LD + 16 * To + ((4 * q) ^ (LTR_STG_SWZ ? 4 * ((crow >> 1) & 3) : 0))) = dz1[To];
                 }
                 __syncthreads();
                 if (!LTR_SKIP(a, 2))
-                    dw_chunk<N::TW1, N::NT1, N::XT, N::BH1, LD>(w, accW1, Ds + q * LD + d, Xs + (64 * c + q) * LD + d);
+                    dw_chunk<N::TW1, N::NT1, N::XT, N::BH1, LD>(w, accW1, Ds + q * LD + (d ^ (LTR_STG_SWZ ? 4 * (q >> 1) : 0)),
+                                                                Xs + (64 * c + q) * LD + d,
+                                                                Ds + q * LD + (d ^ (LTR_STG_SWZ ? 4 * (2 + (q >> 1)) : 0)),
+                                                                Xs + (64 * c + q) * LD + d);
             }
         }
         LTR_STAMP(9)
