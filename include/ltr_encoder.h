@@ -37,7 +37,8 @@ int ltr_enc_sum_partials(const float *parts, int nsplit, int64_t n, int accumula
 typedef struct ltr_reduce_job {
     const float *parts;
     float *out;
-    int64_t n;
+    int64_t n;          /* outputs */
+    int64_t stride;     /* floats between consecutive partial rows; 0 = n (a job may reduce a column slice of wider rows) */
     int32_t nsplit, reserved;
 } ltr_reduce_job;
 int ltr_enc_sum_partials_batch(const ltr_reduce_job *jobs, int njobs, void *stream);
@@ -135,6 +136,28 @@ int ltr_enc_score_bwd(const float *x, const float *a, const float *b, const floa
 int ltr_enc_tail_approxndcg(const float *x, const float *a, const float *b, const float *w, const float *bias, const float *labels,
                             int B, int S, int d, float ln_eps, int norm, float alpha, float eps, float pad, float grad_scale,
                             float *slate_loss, float *scores, float *dx, float *partials, void *stream);
+
+/* ---- The whole network in two calls (csrc/ltr_encoder_host.hip): the launch sequence of LTRModel.forward / backward
+ * (multiLayer.py:74-81) issued from C++.  `params` / `grads`: host arrays of n_params device pointers (fp32) in this order:
+ *   [input_norm.weight, input_norm.bias]                       if input_norm
+ *   fc[i].weight [out][in], fc[i].bias                         per FC layer
+ *   per encoder block: norm1.a_2, norm1.b_2, Wq, bq, Wk, bk, Wv, bv, Wo, bo, norm2.a_2, norm2.b_2, W1, b1, W2, b2
+ *   encoder.norm.a_2, encoder.norm.b_2                         if has_encoder
+ *   output w_1.weight [1][d_model], w_1.bias [1]
+ * `workspace`: ltr_enc_workspace_bytes(spec, B, S) bytes, 256-byte aligned, untouched between the forward and its
+ * backward (it holds the saved activations).  `mask` [B][S] uint8, 1 = padded document (required with an encoder).
+ * ltr_enc_backward overwrites every grads[i] with d (sum_t dscores[t] * scores[t]) / d params[i]. */
+#define LTR_ENC_MAX_FC 8
+typedef struct ltr_enc_spec {
+    int32_t n_features, n_fc, fc_sizes[LTR_ENC_MAX_FC], input_norm, has_encoder, n_layers, heads, d_ff;
+    float fc_dropout, enc_dropout;
+} ltr_enc_spec;
+int64_t ltr_enc_workspace_bytes(const ltr_enc_spec *spec, int B, int S);      /* < 0: LTR_ERR_* */
+int ltr_enc_forward(const ltr_enc_spec *spec, const float *x, const uint8_t *mask, int B, int S, const float *const *params,
+                    int n_params, uint64_t seed, int training, void *workspace, float *scores, void *stream);
+int ltr_enc_backward(const ltr_enc_spec *spec, const float *x, const uint8_t *mask, int B, int S, const float *const *params,
+                     int n_params, uint64_t seed, int training, const float *dscores, void *workspace, float *const *grads,
+                     void *stream);
 
 #ifdef __cplusplus
 }

@@ -94,7 +94,8 @@ class LTRModel(nn.Module):
 
     def forward(self, x, mask, indices):
         spec = self._ltr_spec(x.shape[-1])
-        return _enc.EncoderScores.apply(spec, x, mask, self._ltr_next_seed(), self.training, *self._ltr_params())
+        fn = _enc.EncoderScoresNative if _enc.native_enabled(spec) else _enc.EncoderScores
+        return fn.apply(spec, x, mask, self._ltr_next_seed(), self.training, *self._ltr_params())
 
     def score(self, x, mask, indices):
         return self.forward(x, mask, indices)

@@ -119,8 +119,9 @@ __global__ void cast_bf16_kernel(const float *__restrict__ src, bf16_t *__restri
 // out[e] = sum_z parts[z][e] in a fixed order: 256 threads = ZL z-lanes x EW outputs (EW = 256 / ZL consecutive e, so
 // loads stay coalesced); z-lane l sums z = l, l + ZL, ... in fp64, the ZL lane sums are then added in lane order.
 template <int ZL>
-__device__ __forceinline__ void sum_partials_body(const float *__restrict__ parts, int nsplit, long long n, int accumulate,
-                                                  float *__restrict__ out, int block, int nblocks, double *red /* LDS [256] */) {
+__device__ __forceinline__ void sum_partials_body(const float *__restrict__ parts, int nsplit, long long n, long long stride,
+                                                  int accumulate, float *__restrict__ out, int block, int nblocks,
+                                                  double *red /* LDS [256] */) {
     constexpr int EW = 256 / ZL;
     const int el = threadIdx.x % EW, zl = threadIdx.x / EW;
     for (long long e0 = (long long)block * EW; e0 < n; e0 += (long long)nblocks * EW) {
@@ -129,12 +130,12 @@ __device__ __forceinline__ void sum_partials_body(const float *__restrict__ part
         if (e < n) {
             int z = zl;
             for (; z + 3 * ZL < nsplit; z += 4 * ZL) {
-                s0 += (double)parts[(long long)z * n + e];
-                s1 += (double)parts[(long long)(z + ZL) * n + e];
-                s2 += (double)parts[(long long)(z + 2 * ZL) * n + e];
-                s3 += (double)parts[(long long)(z + 3 * ZL) * n + e];
+                s0 += (double)parts[(long long)z * stride + e];
+                s1 += (double)parts[(long long)(z + ZL) * stride + e];
+                s2 += (double)parts[(long long)(z + 2 * ZL) * stride + e];
+                s3 += (double)parts[(long long)(z + 3 * ZL) * stride + e];
             }
-            for (; z < nsplit; z += ZL) s0 += (double)parts[(long long)z * n + e];
+            for (; z < nsplit; z += ZL) s0 += (double)parts[(long long)z * stride + e];
         }
         double s = (s0 + s1) + (s2 + s3);
         if (ZL > 1) {
@@ -152,18 +153,18 @@ __device__ __forceinline__ void sum_partials_body(const float *__restrict__ part
 }
 // few outputs: spend the threads on the split axis; many outputs: one thread per output
 __host__ __device__ inline int reduce_zl(int nsplit, long long n) { return (n >= 65536 || nsplit < 8) ? 1 : (n >= 4096 ? 4 : 16); }
-__device__ __forceinline__ void sum_partials_any(const float *parts, int nsplit, long long n, int accumulate, float *out, int block,
-                                                 int nblocks, double *red) {
+__device__ __forceinline__ void sum_partials_any(const float *parts, int nsplit, long long n, long long stride, int accumulate,
+                                                 float *out, int block, int nblocks, double *red) {
     switch (reduce_zl(nsplit, n)) {        // workgroup-uniform
-        case 1: sum_partials_body<1>(parts, nsplit, n, accumulate, out, block, nblocks, red); break;
-        case 4: sum_partials_body<4>(parts, nsplit, n, accumulate, out, block, nblocks, red); break;
-        default: sum_partials_body<16>(parts, nsplit, n, accumulate, out, block, nblocks, red); break;
+        case 1: sum_partials_body<1>(parts, nsplit, n, stride, accumulate, out, block, nblocks, red); break;
+        case 4: sum_partials_body<4>(parts, nsplit, n, stride, accumulate, out, block, nblocks, red); break;
+        default: sum_partials_body<16>(parts, nsplit, n, stride, accumulate, out, block, nblocks, red); break;
     }
 }
 __global__ void __launch_bounds__(256) sum_partials_kernel(const float *__restrict__ parts, int nsplit, long long n, int accumulate,
                                                            float *__restrict__ out) {
     __shared__ double red[256];
-    sum_partials_any(parts, nsplit, n, accumulate, out, blockIdx.x, gridDim.x, red);
+    sum_partials_any(parts, nsplit, n, n, accumulate, out, blockIdx.x, gridDim.x, red);
 }
 // up to kReduceJobs independent reductions in one launch (blockIdx.y = job): the backward of one training step ends in
 // ~60 of them, each a few microseconds of work
@@ -172,6 +173,7 @@ struct ReduceJobs {
     const float *parts[kReduceJobs];
     float *out[kReduceJobs];
     long long n[kReduceJobs];
+    long long stride[kReduceJobs];
     int nsplit[kReduceJobs];
     int blocks[kReduceJobs];
 };
@@ -179,7 +181,7 @@ __global__ void __launch_bounds__(256) sum_partials_batch_kernel(ReduceJobs j) {
     __shared__ double red[256];
     const int k = blockIdx.y;
     if ((int)blockIdx.x >= j.blocks[k]) return;
-    sum_partials_any(j.parts[k], j.nsplit[k], j.n[k], 0, j.out[k], blockIdx.x, j.blocks[k], red);
+    sum_partials_any(j.parts[k], j.nsplit[k], j.n[k], j.stride[k], 0, j.out[k], blockIdx.x, j.blocks[k], red);
 }
 
 // ------------------------------------------------------------------------------------------- wave helpers
@@ -1970,11 +1972,12 @@ int ltr_enc_sum_partials_batch(const ltr_reduce_job *jobs, int njobs, void *stre
         for (int k = j0; k < njobs && cnt < kReduceJobs; ++k) {
             const ltr_reduce_job &q = jobs[k];
             if (!q.parts || !q.out) return LTR_ERR_NULL;
-            if (q.nsplit < 1 || q.n < 0) return LTR_ERR_SHAPE;
+            if (q.nsplit < 1 || q.n < 0 || (q.stride != 0 && q.stride < q.n)) return LTR_ERR_SHAPE;
             if (q.n == 0) continue;
             r.parts[cnt] = q.parts;
             r.out[cnt] = q.out;
             r.n[cnt] = q.n;
+            r.stride[cnt] = q.stride > 0 ? q.stride : q.n;
             r.nsplit[cnt] = q.nsplit;
             r.blocks[cnt] = elt_grid(q.n, 256 / reduce_zl(q.nsplit, q.n));
             maxb = r.blocks[cnt] > maxb ? r.blocks[cnt] : maxb;

@@ -61,6 +61,9 @@ _PROTOTYPES = {
     "ltr_enc_ffn_bwd_w": (c_int, [P, P, P, P, P, c_int64, c_int, c_int, c_float, c_uint64, c_int, c_int, P, P, P, P]),
     "ltr_enc_tail_approxndcg": (c_int, [P, P, P, P, P, P, c_int, c_int, c_int, c_float, c_int, c_float, c_float, c_float, c_float,
                                         P, P, P, P, P]),
+    "ltr_enc_workspace_bytes": (c_int64, [P, c_int, c_int]),
+    "ltr_enc_forward": (c_int, [P, P, P, c_int, c_int, P, c_int, c_uint64, c_int, P, P, P]),
+    "ltr_enc_backward": (c_int, [P, P, P, c_int, c_int, P, c_int, c_uint64, c_int, P, P, P, P]),
     "ltr_enc_score_fwd": (c_int, [P, P, P, P, P, c_int64, c_int, c_float, c_int, P, P]),
     "ltr_enc_score_bwd": (c_int, [P, P, P, P, P, c_int64, c_int, c_float, c_int, P, P, c_int, P]),
     "ltr_ordinal_num_blocks": (c_int64, [c_int64]),

@@ -57,8 +57,8 @@ def cast_bf16(src):
 
 class ReduceJob(ctypes.Structure):
     """struct ltr_reduce_job of include/ltr_encoder.h."""
-    _fields_ = [("parts", ctypes.c_void_p), ("out", ctypes.c_void_p), ("n", ctypes.c_int64), ("nsplit", ctypes.c_int32),
-                ("reserved", ctypes.c_int32)]
+    _fields_ = [("parts", ctypes.c_void_p), ("out", ctypes.c_void_p), ("n", ctypes.c_int64), ("stride", ctypes.c_int64),
+                ("nsplit", ctypes.c_int32), ("reserved", ctypes.c_int32)]
 
 
 class deferred_reductions:
@@ -85,7 +85,7 @@ def sum_partials(parts, nsplit, n, out=None, accumulate=False):
     q = deferred_reductions.current
     if q is not None and out is None and not accumulate:
         out = torch.empty(n, dtype=torch.float32, device=parts.device)
-        q.jobs.append(ReduceJob(parts.data_ptr(), out.data_ptr(), n, nsplit, 0))
+        q.jobs.append(ReduceJob(parts.data_ptr(), out.data_ptr(), n, 0, nsplit, 0))
         q.keep += [parts, out]
         return out
     if out is None:
@@ -447,6 +447,98 @@ def _body_backward(spec, seed, st, dx, tail):
         scratch = torch.zeros((T, F), dtype=torch.float32, device=dev)
         grads[0], grads[1] = layernorm_bwd(st["xin"], prm[0], dx, T, F, STD_LN_EPS, 1, scratch)
     return grads
+
+
+class EncSpec(ctypes.Structure):
+    """struct ltr_enc_spec of include/ltr_encoder.h."""
+    _fields_ = [("n_features", ctypes.c_int32), ("n_fc", ctypes.c_int32), ("fc_sizes", ctypes.c_int32 * 8),
+                ("input_norm", ctypes.c_int32), ("has_encoder", ctypes.c_int32), ("n_layers", ctypes.c_int32),
+                ("heads", ctypes.c_int32), ("d_ff", ctypes.c_int32), ("fc_dropout", ctypes.c_float), ("enc_dropout", ctypes.c_float)]
+
+
+def _c_spec(spec):
+    c = EncSpec()
+    c.n_features, c.n_fc = spec.n_features, len(spec.fc_sizes)
+    for i, v in enumerate(spec.fc_sizes):
+        c.fc_sizes[i] = v
+    c.input_norm, c.has_encoder, c.n_layers = int(spec.input_norm), int(spec.has_encoder), spec.n_layers
+    c.heads, c.d_ff, c.fc_dropout, c.enc_dropout = spec.heads, spec.d_ff, spec.fc_dropout, spec.enc_dropout
+    return c
+
+
+def native_enabled(spec):
+    """LTR_ENC_NATIVE=1 selects the C++ orchestrator (csrc/ltr_encoder_host.hip: one FFI call per forward / backward
+    instead of ~450; bit-identical results).  Off by default: measured on the MI355X it is 2 % slower at 256 slates per
+    step (7.71 vs 7.57 ms: per-tensor weight casts, no allocator reuse of hot buffers) and equal at 16-64 slates, where
+    the step is bound by the GPU-side dispatch of ~450 small kernels, not by Python.  It is the entry point for
+    non-Python hosts."""
+    import os
+    return os.environ.get("LTR_ENC_NATIVE", "0") == "1" and len(spec.fc_sizes) <= 8
+
+
+class EncoderScoresNative(torch.autograd.Function):
+    """EncoderScores with the launch sequence issued from C++ (ltr_enc_forward / ltr_enc_backward)."""
+
+    @staticmethod
+    def forward(ctx, spec, x, mask, seed, training, *params):
+        if len(params) != spec.n_params():
+            raise ValueError(f"expected {spec.n_params()} parameter tensors, got {len(params)}")
+        require_device(x, *params)
+        if x.dim() != 3 or x.shape[2] != spec.n_features:
+            raise ValueError(f"input must be [batch, slate, {spec.n_features}], got {tuple(x.shape)}")
+        B, S, F = x.shape
+        if spec.has_encoder and S > 512:
+            raise ValueError("the attention kernels hold a whole slate: slate_length <= 512")
+        if spec.has_encoder and mask is None:
+            raise AttributeError("'NoneType' object has no attribute 'unsqueeze'")      # transformer.py:55
+        if params[-2].shape[0] != 1:
+            raise NotImplementedError("OutputLayer with d_output > 1 is not built on the HIP path")
+        ctx.param_dtypes = [p.dtype for p in params]
+        ctx.shapes = [tuple(p.shape) for p in params]
+        if B * S == 0:
+            ctx.ws = None
+            return torch.empty((B, S), dtype=torch.float32, device=x.device)
+        dev = x.device
+        with torch.cuda.device(dev):
+            cs = _c_spec(spec)
+            nbytes = lib().ltr_enc_workspace_bytes(ctypes.byref(cs), B, S)
+            if nbytes < 0:
+                check(int(nbytes), "ltr_enc_workspace_bytes")
+            ws = torch.empty(nbytes + 256, dtype=torch.uint8, device=dev)
+            ws_ptr = (ws.data_ptr() + 255) & ~255
+            xin = x.detach().to(torch.float32).contiguous()
+            prm = [p.detach().to(torch.float32).contiguous() for p in params]
+            pp = (ctypes.c_void_p * len(prm))(*[p.data_ptr() for p in prm])
+            mask_u8 = (mask.to(dev) == 1).to(torch.uint8).contiguous() if spec.has_encoder else None
+            scores = torch.empty((B, S), dtype=torch.float32, device=dev)
+            check(lib().ltr_enc_forward(ctypes.byref(cs), _ptr(xin), _ptr(mask_u8), B, S, pp, len(prm), int(seed) & (2 ** 64 - 1),
+                                        int(bool(training)), ws_ptr, _ptr(scores), _stream()), "ltr_enc_forward")
+        ctx.spec, ctx.cs, ctx.seed, ctx.training = spec, cs, int(seed) & (2 ** 64 - 1), bool(training)
+        ctx.ws, ctx.ws_ptr, ctx.xin, ctx.prm, ctx.mask_u8, ctx.dims = ws, ws_ptr, xin, prm, mask_u8, (B, S)
+        return scores
+
+    @staticmethod
+    def backward(ctx, dscores):
+        dev = dscores.device
+        if ctx.ws is None:
+            zeros = [torch.zeros(sh, dtype=dt, device=dev) for sh, dt in zip(ctx.shapes, ctx.param_dtypes)]
+            return (None, None, None, None, None, *zeros)
+        B, S = ctx.dims
+        prm = ctx.prm
+        with torch.cuda.device(dev):
+            ds = dscores.detach().to(torch.float32).contiguous()
+            sizes = [(p.numel() + 63) // 64 * 64 for p in prm]                    # 256-byte aligned pieces of one buffer
+            flat = torch.empty(sum(sizes), dtype=torch.float32, device=dev)
+            offs = [0]
+            for n in sizes:
+                offs.append(offs[-1] + n)
+            gviews = [flat[o:o + p.numel()].view(p.shape) for o, p in zip(offs, prm)]
+            pp = (ctypes.c_void_p * len(prm))(*[p.data_ptr() for p in prm])
+            gp = (ctypes.c_void_p * len(prm))(*[g.data_ptr() for g in gviews])
+            check(lib().ltr_enc_backward(ctypes.byref(ctx.cs), _ptr(ctx.xin), _ptr(ctx.mask_u8), B, S, pp, len(prm), ctx.seed,
+                                         int(ctx.training), _ptr(ds), ctx.ws_ptr, gp, _stream()), "ltr_enc_backward")
+        out = [g.to(dt) for g, dt in zip(gviews, ctx.param_dtypes)]
+        return (None, None, None, None, None, *out)
 
 
 class EncoderApproxNDCG(torch.autograd.Function):

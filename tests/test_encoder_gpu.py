@@ -460,6 +460,35 @@ def test_fused_tail_loss_matches_the_two_call_form(enc, with_encoder):
             assert e < (2e-4 if tail else 3e-2), (B, S, k, e)
 
 
+@pytest.mark.parametrize("fc,tr", [
+    (dict(sizes=[128], input_norm=False, activation=None, dropout=0.1), dict(N=2, d_ff=256, h=8, dropout=0.1, positional_encoding=None)),
+    (dict(sizes=[48, 40], input_norm=True, activation=None, dropout=0.2), dict(N=1, d_ff=64, h=5, dropout=0.1, positional_encoding=None)),
+    (None, dict(N=2, d_ff=64, h=8, dropout=0.0, positional_encoding=None)),
+    (dict(sizes=[32, 16], input_norm=True, activation=None, dropout=0.0), None)])
+def test_native_orchestrator_matches_python_path(enc, fc, tr):
+    """ltr_enc_forward / ltr_enc_backward (launch sequence issued from C++) vs the Python-driven sequence: the same
+    kernels with the same arguments in the same order, so scores and every gradient are bit-identical."""
+    from architeture.multiLayer import make_model
+    import copy
+    torch.manual_seed(21)
+    net = make_model(copy.deepcopy(fc), copy.deepcopy(tr), dict(d_output=1), 136).to(DEV).train()
+    spec, params = net._ltr_spec(136), net._ltr_params()
+    for B, S in ((3, 100), (2, 256), (1, 5)):
+        x = torch.randn(B, S, 136, device=DEV)
+        mask = torch.zeros(B, S, dtype=torch.bool, device=DEV)
+        mask[0, S - 1] = True
+        w = torch.randn(B, S, device=DEV)
+        outs = []
+        for fn in (enc.EncoderScores, enc.EncoderScoresNative):
+            net.zero_grad()
+            s_ = fn.apply(spec, x, mask if tr else None, 4242, True, *params)
+            (s_ * w).sum().backward()
+            outs.append((s_.detach().clone(), [p.grad.clone() for p in params]))
+        assert torch.equal(outs[0][0], outs[1][0])
+        for k, (ga, gb) in enumerate(zip(outs[0][1], outs[1][1])):
+            assert torch.equal(ga, gb), (B, S, k, float((ga - gb).abs().max()))
+
+
 def test_network_edge_shapes(enc):
     """Empty batch, one-document slates, tiny and ragged slate lengths, every mask dtype the callers use."""
     import ltr_encoder_oracle as EO
