@@ -1170,36 +1170,40 @@ __device__ __forceinline__ u32x4 tok_frag(const bf16_t *__restrict__ base, long 
 
 // hidden pre-activations of the wave's two token tiles for hidden tile ht of the chunk in LDS:
 // z[tt][r] = (W1c x^T)[hidden 16 ht + 4 q + r][token (lane & 15) of tile tt]
-template <int D, int LD>
-__device__ __forceinline__ void ffn_z(const bf16_t *w1img, int ht, const u32x4 (&xf)[2][D / 32], f32x4 (&z)[2], int lane) {
-    z[0] = z[1] = f32x4{0.f, 0.f, 0.f, 0.f};
+template <int D, int LD, int TT>
+__device__ __forceinline__ void ffn_z(const bf16_t *w1img, int ht, const u32x4 (&xf)[TT][D / 32], f32x4 (&z)[TT], int lane) {
+#pragma unroll
+    for (int tt = 0; tt < TT; ++tt) z[tt] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int k = 0; k < D / 32; ++k) {
         const u32x4 a = D == 128 ? sw_row_frag(w1img, sw_row_lane(lane), ht, k)
                                  : *reinterpret_cast<const u32x4 *>(w1img + (16 * ht + (lane & 15)) * LD + 32 * k + 8 * (lane >> 4));
-        z[0] = mfma_bf16(a, xf[0][k], z[0]);
-        z[1] = mfma_bf16(a, xf[1][k], z[1]);
+#pragma unroll
+        for (int tt = 0; tt < TT; ++tt) z[tt] = mfma_bf16(a, xf[tt][k], z[tt]);
     }
 }
 
-template <int D>
+// TT = token tiles (of 16) per wave: 2 -> 256 tokens per workgroup; 1 -> 128 (twice the workgroups when T is small)
+template <int D, int TT>
 __global__ void __launch_bounds__(kFfnThreads) ffn_fwd_kernel(FfnArgs a) {
     extern __shared__ __attribute__((aligned(16))) bf16_t smem[];
     constexpr int DK = D / 32, DT = D / 16, LD1 = D == 128 ? 128 : D + 8, LD2 = D == 128 ? 128 : kFfnChunk + 8;
     constexpr bool DMA = D == 128;        // swizzled 256-byte-row images filled by LDS-DMA
     constexpr int IMG = kFfnChunk * LD1 + D * LD2;           // W1c [128][LD1] then W2c [D][LD2]
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, j = lane & 15, q = lane >> 4;
-    const long long tok0 = (long long)blockIdx.x * kFfnTok + 32 * w;
+    const long long tok0 = (long long)blockIdx.x * (128 * TT) + 16 * TT * w;
     const unsigned thr = drop_threshold(a.p);
     const float ks = thr ? 1.f / (1.f - a.p) : 1.f;
-    u32x4 xf[2][DK];
+    u32x4 xf[TT][DK];
 #pragma unroll
-    for (int tt = 0; tt < 2; ++tt)
+    for (int tt = 0; tt < TT; ++tt)
 #pragma unroll
         for (int k = 0; k < DK; ++k) xf[tt][k] = tok_frag<false>(a.n2, tok0 + 16 * tt + j, a.T, D, k, q);
-    f32x4 y[DT][2];
+    f32x4 y[DT][TT];
 #pragma unroll
-    for (int dt = 0; dt < DT; ++dt) y[dt][0] = y[dt][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+        for (int tt = 0; tt < TT; ++tt) y[dt][tt] = f32x4{0.f, 0.f, 0.f, 0.f};
     const int nc = a.dff / kFfnChunk;
     u32x4 r1[kFfnChunk * D / 8 / kFfnThreads], r2[D * kFfnChunk / 8 / kFfnThreads];
     const DmaLane L1 = dma_lane(D), L2 = dma_lane(a.dff);
@@ -1228,15 +1232,15 @@ __global__ void __launch_bounds__(kFfnThreads) ffn_fwd_kernel(FfnArgs a) {
                 ffn_store<D, kFfnChunk, LD2>(nx + kFfnChunk * LD1, r2);
             }
         }
-        u32x2 hb[8][2];
+        u32x2 hb[8][TT];
 #pragma unroll
         for (int ht = 0; ht < 8; ++ht) {
-            f32x4 z[2];
-            ffn_z<D, LD1>(w1img, ht, xf, z, lane);
+            f32x4 z[TT];
+            ffn_z<D, LD1, TT>(w1img, ht, xf, z, lane);
             const int h0 = c * kFfnChunk + 16 * ht + 4 * q;
             const f32x4 bias = *reinterpret_cast<const f32x4 *>(a.b1 + h0);
 #pragma unroll
-            for (int tt = 0; tt < 2; ++tt) {
+            for (int tt = 0; tt < TT; ++tt) {
                 f32x4 v = z[tt] + bias;
                 const unsigned keep = thr ? drop_keep4(a.seed, a.stream_hidden, (unsigned long long)(tok0 + 16 * tt + j) * a.dff + h0, thr) : 15u;
 #pragma unroll
@@ -1247,8 +1251,9 @@ __global__ void __launch_bounds__(kFfnThreads) ffn_fwd_kernel(FfnArgs a) {
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            const u32x4 b0 = {hb[2 * u][0][0], hb[2 * u][0][1], hb[2 * u + 1][0][0], hb[2 * u + 1][0][1]};
-            const u32x4 b1v = {hb[2 * u][1][0], hb[2 * u][1][1], hb[2 * u + 1][1][0], hb[2 * u + 1][1][1]};
+            u32x4 bfr[TT];
+#pragma unroll
+            for (int tt = 0; tt < TT; ++tt) bfr[tt] = u32x4{hb[2 * u][tt][0], hb[2 * u][tt][1], hb[2 * u + 1][tt][0], hb[2 * u + 1][tt][1]};
 #pragma unroll
             for (int dt = 0; dt < DT; ++dt) {
                 u32x4 af;
@@ -1258,8 +1263,8 @@ __global__ void __launch_bounds__(kFfnThreads) ffn_fwd_kernel(FfnArgs a) {
                     const u32x2 lo = *reinterpret_cast<const u32x2 *>(pr), hi = *reinterpret_cast<const u32x2 *>(pr + 16);
                     af = u32x4{lo[0], lo[1], hi[0], hi[1]};
                 }
-                y[dt][0] = mfma_bf16(af, b0, y[dt][0]);
-                y[dt][1] = mfma_bf16(af, b1v, y[dt][1]);
+#pragma unroll
+                for (int tt = 0; tt < TT; ++tt) y[dt][tt] = mfma_bf16(af, bfr[tt], y[dt][tt]);
             }
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -1269,7 +1274,7 @@ __global__ void __launch_bounds__(kFfnThreads) ffn_fwd_kernel(FfnArgs a) {
     // y^T tiles: lane = token, registers = 4 consecutive d
     const unsigned thro = drop_threshold(a.p);
 #pragma unroll
-    for (int tt = 0; tt < 2; ++tt) {
+    for (int tt = 0; tt < TT; ++tt) {
         const long long tok = tok0 + 16 * tt + j;
         if (tok >= a.T) continue;
 #pragma unroll
@@ -1287,7 +1292,7 @@ __global__ void __launch_bounds__(kFfnThreads) ffn_fwd_kernel(FfnArgs a) {
     }
 }
 
-template <int D>
+template <int D, int TT>
 __global__ void __launch_bounds__(kFfnThreads) ffn_bwd_x_kernel(FfnArgs a) {
     extern __shared__ __attribute__((aligned(16))) bf16_t smem[];
     constexpr bool DMA = D == 128;        // swizzled 256-byte-row images filled by LDS-DMA
@@ -1295,20 +1300,22 @@ __global__ void __launch_bounds__(kFfnThreads) ffn_bwd_x_kernel(FfnArgs a) {
     constexpr int IMG = kFfnChunk * LD1 + D * LD2;
     static_assert(DMA || (LD1 / 2) % 64 == 8 || (LD1 / 2) % 64 == 24 || (LD1 / 2) % 64 == 40 || (LD1 / 2) % 64 == 56, "transposed-read stride");
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, j = lane & 15, q = lane >> 4;
-    const long long tok0 = (long long)blockIdx.x * kFfnTok + 32 * w;
+    const long long tok0 = (long long)blockIdx.x * (128 * TT) + 16 * TT * w;
     const unsigned thr = drop_threshold(a.p);
     const float ks = thr ? 1.f / (1.f - a.p) : 1.f;
-    u32x4 xf[2][DK], dyf[2][DK];
+    u32x4 xf[TT][DK], dyf[TT][DK];
 #pragma unroll
-    for (int tt = 0; tt < 2; ++tt)
+    for (int tt = 0; tt < TT; ++tt)
 #pragma unroll
         for (int k = 0; k < DK; ++k) {
             xf[tt][k] = tok_frag<false>(a.n2, tok0 + 16 * tt + j, a.T, D, k, q);
             dyf[tt][k] = tok_frag<true>(a.dy, tok0 + 16 * tt + j, a.T, D, k, q);
         }
-    f32x4 dn[DT][2];
+    f32x4 dn[DT][TT];
 #pragma unroll
-    for (int dt = 0; dt < DT; ++dt) dn[dt][0] = dn[dt][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+        for (int tt = 0; tt < TT; ++tt) dn[dt][tt] = f32x4{0.f, 0.f, 0.f, 0.f};
     const int nc = a.dff / kFfnChunk;
     const DmaLane L1 = dma_lane(D), L2 = dma_lane(a.dff);
     if (DMA) {
@@ -1333,16 +1340,16 @@ __global__ void __launch_bounds__(kFfnThreads) ffn_bwd_x_kernel(FfnArgs a) {
             }
         }
         // gate bits: the hidden unit is alive (relu) and kept (dropout)
-        unsigned gate[2] = {0u, 0u};          // bit 4 ht + r of word tt
+        unsigned gate[TT] = {};               // bit 4 ht + r of word tt
         {
 #pragma unroll
             for (int ht = 0; ht < 8; ++ht) {
-                f32x4 z[2];
-                ffn_z<D, LD1>(w1img, ht, xf, z, lane);
+                f32x4 z[TT];
+                ffn_z<D, LD1, TT>(w1img, ht, xf, z, lane);
                 const int h0 = c * kFfnChunk + 16 * ht + 4 * q;
                 const f32x4 bias = *reinterpret_cast<const f32x4 *>(a.b1 + h0);
 #pragma unroll
-                for (int tt = 0; tt < 2; ++tt) {
+                for (int tt = 0; tt < TT; ++tt) {
                     const unsigned keep = thr ? drop_keep4(a.seed, a.stream_hidden, (unsigned long long)(tok0 + 16 * tt + j) * a.dff + h0, thr) : 15u;
                     unsigned bits = 0u;
 #pragma unroll
@@ -1357,35 +1364,37 @@ __global__ void __launch_bounds__(kFfnThreads) ffn_bwd_x_kernel(FfnArgs a) {
             }
         }
         // dh^T = W2c^T dy^T (A: transposed read of the [d][hidden] image), gated -> dz^T as the next B operand
-        u32x2 dzb[8][2];
+        u32x2 dzb[8][TT];
 #pragma unroll
         for (int ht = 0; ht < 8; ++ht) {
-            f32x4 dh0 = {0.f, 0.f, 0.f, 0.f}, dh1 = dh0;
+            f32x4 dh[TT];
+#pragma unroll
+            for (int tt = 0; tt < TT; ++tt) dh[tt] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int k = 0; k < DK; ++k) {
                 const u32x4 af = DMA ? sw_tr_frag(w2img, sw_tr_lane(lane), 32 * k, ht) : tr_frag<LD2>(w2img, 32 * k, ht, lane);
-                dh0 = mfma_bf16(af, dyf[0][k], dh0);
-                dh1 = mfma_bf16(af, dyf[1][k], dh1);
+#pragma unroll
+                for (int tt = 0; tt < TT; ++tt) dh[tt] = mfma_bf16(af, dyf[tt][k], dh[tt]);
             }
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                dh0[r] = (gate[0] >> (4 * ht + r)) & 1u ? dh0[r] * ks : 0.f;
-                dh1[r] = (gate[1] >> (4 * ht + r)) & 1u ? dh1[r] * ks : 0.f;
+            for (int tt = 0; tt < TT; ++tt) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) dh[tt][r] = (gate[tt] >> (4 * ht + r)) & 1u ? dh[tt][r] * ks : 0.f;
+                dzb[ht][tt] = u32x2{pack_bf16(dh[tt][0], dh[tt][1]), pack_bf16(dh[tt][2], dh[tt][3])};
             }
-            dzb[ht][0] = u32x2{pack_bf16(dh0[0], dh0[1]), pack_bf16(dh0[2], dh0[3])};
-            dzb[ht][1] = u32x2{pack_bf16(dh1[0], dh1[1]), pack_bf16(dh1[2], dh1[3])};
             __builtin_amdgcn_sched_barrier(0);
         }
         // dn2^T += W1c^T dz^T (A: transposed read of the [hidden][d] image)
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            const u32x4 b0 = {dzb[2 * u][0][0], dzb[2 * u][0][1], dzb[2 * u + 1][0][0], dzb[2 * u + 1][0][1]};
-            const u32x4 b1v = {dzb[2 * u][1][0], dzb[2 * u][1][1], dzb[2 * u + 1][1][0], dzb[2 * u + 1][1][1]};
+            u32x4 bfr[TT];
+#pragma unroll
+            for (int tt = 0; tt < TT; ++tt) bfr[tt] = u32x4{dzb[2 * u][tt][0], dzb[2 * u][tt][1], dzb[2 * u + 1][tt][0], dzb[2 * u + 1][tt][1]};
 #pragma unroll
             for (int dt = 0; dt < DT; ++dt) {
                 const u32x4 af = DMA ? sw_tr_frag(w1img, sw_tr_lane(lane), 32 * u, dt) : tr_frag<LD1>(w1img, 32 * u, dt, lane);
-                dn[dt][0] = mfma_bf16(af, b0, dn[dt][0]);
-                dn[dt][1] = mfma_bf16(af, b1v, dn[dt][1]);
+#pragma unroll
+                for (int tt = 0; tt < TT; ++tt) dn[dt][tt] = mfma_bf16(af, bfr[tt], dn[dt][tt]);
             }
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -1393,7 +1402,7 @@ __global__ void __launch_bounds__(kFfnThreads) ffn_bwd_x_kernel(FfnArgs a) {
         __syncthreads();
     }
 #pragma unroll
-    for (int tt = 0; tt < 2; ++tt) {
+    for (int tt = 0; tt < TT; ++tt) {
         const long long tok = tok0 + 16 * tt + j;
         if (tok >= a.T) continue;
 #pragma unroll
@@ -2084,10 +2093,15 @@ int ltr_enc_ffn_fwd(const uint16_t *n2, const uint16_t *w1, const float *b1, con
     if (T == 0) return LTR_OK;
     FfnArgs a{n2, w1, w2, nullptr, b1, b2, x1, (long long)T, dff, drop_p, (unsigned long long)seed, stream_hidden, stream_out, x2,
               nullptr, nullptr, nullptr, 0};
-    const dim3 grid((unsigned)((T + kFfnTok - 1) / kFfnTok));
-    static bool d64[64] = {}, d128[64] = {};
-    if (d == 64) return ffn_launch(ffn_fwd_kernel<64>, d64, grid, 2 * (kFfnChunk * (64 + 8) + 64 * (kFfnChunk + 8)) * sizeof(bf16_t), a, (hipStream_t)stream);
-    return ffn_launch(ffn_fwd_kernel<128>, d128, grid, 2 * 2 * 128 * 128 * sizeof(bf16_t), a, (hipStream_t)stream);
+    // 256 tokens per workgroup once that fills the chip; 128 below (twice the workgroups, each streams the weights once)
+    const bool small = T < (int64_t)256 * kFfnTok;
+    const dim3 grid((unsigned)(small ? (T + 127) / 128 : (T + kFfnTok - 1) / kFfnTok));
+    static bool d64[64] = {}, d128[64] = {}, s64[64] = {}, s128[64] = {};
+    const size_t l64 = 2 * (kFfnChunk * (64 + 8) + 64 * (kFfnChunk + 8)) * sizeof(bf16_t), l128 = 2 * 2 * 128 * 128 * sizeof(bf16_t);
+    if (d == 64) return small ? ffn_launch(ffn_fwd_kernel<64, 1>, s64, grid, l64, a, (hipStream_t)stream)
+                              : ffn_launch(ffn_fwd_kernel<64, 2>, d64, grid, l64, a, (hipStream_t)stream);
+    return small ? ffn_launch(ffn_fwd_kernel<128, 1>, s128, grid, l128, a, (hipStream_t)stream)
+                 : ffn_launch(ffn_fwd_kernel<128, 2>, d128, grid, l128, a, (hipStream_t)stream);
 }
 
 int ltr_enc_ffn_bwd_x(const uint16_t *n2, const uint16_t *w1, const float *b1, const uint16_t *w2, const uint16_t *dy, int64_t T, int d,
@@ -2098,10 +2112,14 @@ int ltr_enc_ffn_bwd_x(const uint16_t *n2, const uint16_t *w1, const float *b1, c
     if (T == 0) return LTR_OK;
     FfnArgs a{n2, w1, w2, dy, b1, nullptr, nullptr, (long long)T, dff, drop_p, (unsigned long long)seed, stream_hidden, 0, dn2,
               nullptr, nullptr, nullptr, 0};
-    const dim3 grid((unsigned)((T + kFfnTok - 1) / kFfnTok));
-    static bool d64[64] = {}, d128[64] = {};
-    if (d == 64) return ffn_launch(ffn_bwd_x_kernel<64>, d64, grid, 2 * (kFfnChunk * (64 + 16) + 64 * (kFfnChunk + 16)) * sizeof(bf16_t), a, (hipStream_t)stream);
-    return ffn_launch(ffn_bwd_x_kernel<128>, d128, grid, 2 * 2 * 128 * 128 * sizeof(bf16_t), a, (hipStream_t)stream);
+    const bool small = T < (int64_t)256 * kFfnTok;
+    const dim3 grid((unsigned)(small ? (T + 127) / 128 : (T + kFfnTok - 1) / kFfnTok));
+    static bool d64[64] = {}, d128[64] = {}, s64[64] = {}, s128[64] = {};
+    const size_t l64 = 2 * (kFfnChunk * (64 + 16) + 64 * (kFfnChunk + 16)) * sizeof(bf16_t), l128 = 2 * 2 * 128 * 128 * sizeof(bf16_t);
+    if (d == 64) return small ? ffn_launch(ffn_bwd_x_kernel<64, 1>, s64, grid, l64, a, (hipStream_t)stream)
+                              : ffn_launch(ffn_bwd_x_kernel<64, 2>, d64, grid, l64, a, (hipStream_t)stream);
+    return small ? ffn_launch(ffn_bwd_x_kernel<128, 1>, s128, grid, l128, a, (hipStream_t)stream)
+                 : ffn_launch(ffn_bwd_x_kernel<128, 2>, d128, grid, l128, a, (hipStream_t)stream);
 }
 
 int ltr_enc_ffn_bwd_w(const uint16_t *n2, const uint16_t *w1, const float *b1, const uint16_t *w2, const uint16_t *dy, int64_t T, int d,

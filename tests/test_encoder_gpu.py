@@ -256,10 +256,11 @@ def test_attention_without_mask_and_all_masked_slate(enc):
 
 # ------------------------------------------------------------------------------------------------- fused FFN
 @pytest.mark.parametrize("T,d,dff,p", [(700, 128, 384, 0.1), (256, 128, 128, 0.0), (1000, 64, 256, 0.2), (130, 64, 128, 0.0),
-                                       (4096, 128, 2048, 0.1)])
+                                       (4096, 128, 2048, 0.1), (66000, 128, 256, 0.1), (65536, 64, 128, 0.0)])
 def test_fused_ffn_matches_the_gemm_path(enc, T, d, dff, p):
     """ltr_enc_ffn_* (hidden activation in registers, recomputed in the backward) vs the same sublayer through
-    ltr_enc_gemm_bf16: identical rounding points, so only the fp32 summation order differs."""
+    ltr_enc_gemm_bf16: identical rounding points, so only the fp32 summation order differs.  T < 65 536 takes the
+    128-tokens-per-workgroup variants of the forward / input-gradient kernels, T >= 65 536 the 256-token ones."""
     torch.manual_seed(T + d + dff)
     seed, sh, so = 987654321, 10, 11
     n2, dy = rnd(T, d), rnd(T, d, scale=0.3)
