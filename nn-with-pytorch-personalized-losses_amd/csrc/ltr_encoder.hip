@@ -1410,7 +1410,9 @@ __global__ void __launch_bounds__(kFfnThreads) ffn_bwd_x_kernel(FfnArgs a) {
     }
 }
 
-// workgroup = (chunk c = blockIdx.x, token range blockIdx.y); wave w = hidden units 16 w .. 16 w + 15 of the chunk
+// workgroup = (chunk c, token range rg); wave w = hidden units 16 w .. 16 w + 15 of the chunk.  XCD-aware ids: all chunks
+// of one token range share a residue class mod 8 (one XCD, one L2), so a range's n2 / dy tiles come from HBM once instead
+// of once per XCD (measured: 1.82 -> GB of HBM traffic per step for this kernel)
 template <int D>
 __global__ void __launch_bounds__(kFfnThreads) ffn_bwd_w_kernel(FfnArgs a) {
     extern __shared__ __attribute__((aligned(16))) bf16_t smem[];
@@ -1422,12 +1424,15 @@ __global__ void __launch_bounds__(kFfnThreads) ffn_bwd_w_kernel(FfnArgs a) {
     constexpr int DK = D / 32, DT = D / 16, LD = DMA ? 128 : D + 16, TOK = 128, IMG = 2 * TOK * LD;   // n2 tile then dy tile, [token][d]
     bf16_t *landing = smem + IMG;          // LAND: [2][128][128] behind the single image pair
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, j = lane & 15, q = lane >> 4;
-    const int c = blockIdx.x, hid = c * kFfnChunk + 16 * w + j;          // this lane's hidden unit (as a column)
+    const int nchunk = a.dff / kFfnChunk, xcd = blockIdx.x & 7, nn = blockIdx.x >> 3;
+    const int c = nn % nchunk, rg = (nn / nchunk) * 8 + xcd;               // grid = ceil(nsplit / 8) * 8 * nchunk
+    if (rg >= a.nsplit) return;
+    const int hid = c * kFfnChunk + 16 * w + j;          // this lane's hidden unit (as a column)
     const unsigned thr = drop_threshold(a.p);
     const float ks = thr ? 1.f / (1.f - a.p) : 1.f;
     // token range of this workgroup, whole 128-token tiles
-    const long long tiles = (a.T + TOK - 1) / TOK, per = (tiles + gridDim.y - 1) / gridDim.y;
-    const long long t_beg = (long long)blockIdx.y * per, t_end = t_beg + per < tiles ? t_beg + per : tiles;
+    const long long tiles = (a.T + TOK - 1) / TOK, per = (tiles + a.nsplit - 1) / a.nsplit;
+    const long long t_beg = (long long)rg * per, t_end = t_beg + per < tiles ? t_beg + per : tiles;
     // B operands of the two recomputed products, constant for the wave: W1[hid][d 32k + 8g ..], W2[d 32k + 8g ..][hid]
     u32x4 w1f[DK], w2f[DK];
 #pragma unroll
@@ -1529,7 +1534,7 @@ __global__ void __launch_bounds__(kFfnThreads) ffn_bwd_w_kernel(FfnArgs a) {
             }
         }
     }
-    float *p1 = a.dw1 + (long long)blockIdx.y * a.dff * D, *p2 = a.dw2 + (long long)blockIdx.y * D * a.dff;
+    float *p1 = a.dw1 + (long long)rg * a.dff * D, *p2 = a.dw2 + (long long)rg * D * a.dff;
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
@@ -1539,7 +1544,7 @@ __global__ void __launch_bounds__(kFfnThreads) ffn_bwd_w_kernel(FfnArgs a) {
         }
     db1 += __shfl_xor(db1, 16, 64);
     db1 += __shfl_xor(db1, 32, 64);
-    if (q == 0) a.db1[(long long)blockIdx.y * a.dff + hid] = db1;
+    if (q == 0) a.db1[(long long)rg * a.dff + hid] = db1;
 }
 
 // ------------------------------------------------------------------------------------------- attention
@@ -1586,6 +1591,18 @@ __device__ __forceinline__ void store4(bf16_t *row, int d0, int dk, bool vec, co
     for (int r = 0; r < 4; ++r)
         if (d0 + r < dk) row[d0 + r] = to_bf16(v[r]);
 }
+
+// Workgroup id -> (slate, head), XCD-aware: the hardware deals consecutive workgroup ids round-robin to the 8 XCDs (each
+// with its own L2), and the h heads of one slate read interleaved 2*dk-byte slices of the SAME qkv rows -- so all heads of
+// a slate are given ids of one residue class mod 8 (one XCD): its L2 then fetches every qkv line once instead of once per
+// head.  The grid is ceil(B / 8) * 8 * h; ids whose slate is >= B exit.  Returns false for those.
+__device__ __forceinline__ bool att_slate_head(int B, int h, int &b, int &hd) {
+    const int x = blockIdx.x & 7, n = blockIdx.x >> 3;
+    b = (n / h) * 8 + x;
+    hd = n % h;
+    return b < B;
+}
+inline unsigned att_grid(int B, int h) { return (unsigned)((B + 7) / 8 * 8 * h); }
 
 // stage `which` (0 Q, 1 K, 2 V of qkv; 3 = dctx) of slate b / head hd: row image [Sp][kRowLd] and/or transposed image
 // [32][ldt].  All threads of the workgroup.
@@ -1673,7 +1690,9 @@ __global__ void __launch_bounds__(kAttThreads) attention_fwd_kernel(AttArgs a) {
     const int Sp = round_up(a.S, 32), KT = FULL ? KTMAX : Sp / 16, ldt = tr_ld(Sp);
     bf16_t *Kimg = smem, *VT = Kimg + Sp * kRowLd;
     float *biasS = reinterpret_cast<float *>(VT + kDkPad * ldt);
-    const int b = blockIdx.x / a.h, hd = blockIdx.x % a.h, d = a.h * a.dk;
+    int b, hd;
+    if (!att_slate_head(a.B, a.h, b, hd)) return;
+    const int d = a.h * a.dk, bh = b * a.h + hd;          // bh: index of this (slate, head) in the dropout stream
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, j = lane & 15, g = lane >> 4;
     const bool vec = a.dk % 8 == 0;
     stage_head(a, b, hd, 1, Sp, Kimg, nullptr, 0);
@@ -1705,7 +1724,7 @@ __global__ void __launch_bounds__(kAttThreads) attention_fwd_kernel(AttArgs a) {
                 for (int half = 0; half < 2; ++half) {
                     f32x4 p = st[2 * u + half];
                     if (thr) {
-                        const unsigned keep = drop_keep4(a.seed, a.stream_id, attn_idx(blockIdx.x, Sp, query, 32 * u + 16 * half + 4 * g), thr);
+                        const unsigned keep = drop_keep4(a.seed, a.stream_id, attn_idx(bh, Sp, query, 32 * u + 16 * half + 4 * g), thr);
 #pragma unroll
                         for (int r = 0; r < 4; ++r) p[r] = (keep >> r) & 1u ? p[r] * ks : 0.f;
                     }
@@ -1749,7 +1768,9 @@ __global__ void __launch_bounds__(kAttThreads) attention_bwd_kernel(AttArgs a) {
     // phase A images: K rows, V rows, K^T;  phase B images: Q rows, dO rows, Q^T, dO^T (same memory)
     bf16_t *img0 = smem, *img1 = img0 + Sp * kRowLd, *tr0 = img1 + Sp * kRowLd, *tr1 = tr0 + kDkPad * ldt;
     float *lseS = reinterpret_cast<float *>(tr1 + kDkPad * ldt), *DS = lseS + Sp, *biasS = DS + Sp;       // [Sp] each
-    const int b = blockIdx.x / a.h, hd = blockIdx.x % a.h, d = a.h * a.dk;
+    int b, hd;
+    if (!att_slate_head(a.B, a.h, b, hd)) return;
+    const int d = a.h * a.dk, bh = b * a.h + hd;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, j = lane & 15, g = lane >> 4;
     const bool vec = a.dk % 8 == 0;
     const float scale = 1.f / sqrtf((float)a.dk), c2 = 1.44269504088896341f * scale;
@@ -1795,7 +1816,7 @@ __global__ void __launch_bounds__(kAttThreads) attention_bwd_kernel(AttArgs a) {
                 for (int half = 0; half < 2; ++half) {
                     const int kt = 2 * u + half;
                     const f32x4 dp = mfma_bf16(row_frag(img1, kt, lane), dof, zero);     // dPd^T = V dO^T
-                    const unsigned keep = thr ? drop_keep4(a.seed, a.stream_id, attn_idx(blockIdx.x, Sp, query, 16 * kt + 4 * g), thr) : 15u;
+                    const unsigned keep = thr ? drop_keep4(a.seed, a.stream_id, attn_idx(bh, Sp, query, 16 * kt + 4 * g), thr) : 15u;
                     f32x4 ds;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) ds[r] = st[kt][r] * (((keep >> r) & 1u ? dp[r] * ks : 0.f) - D) * scale;
@@ -1836,7 +1857,7 @@ __global__ void __launch_bounds__(kAttThreads) attention_bwd_kernel(AttArgs a) {
                 const f32x4 l4 = *reinterpret_cast<const f32x4 *>(lseS + 16 * qt + 4 * g);
                 const f32x4 d4 = *reinterpret_cast<const f32x4 *>(DS + 16 * qt + 4 * g);
                 f32x4 pd, ds;
-                const unsigned keep4 = thr ? drop_keep_col4(a.seed, a.stream_id, attn_idx(blockIdx.x, Sp, 16 * qt + 4 * g, key), (unsigned long long)Sp, thr, lane) : 15u;
+                const unsigned keep4 = thr ? drop_keep_col4(a.seed, a.stream_id, attn_idx(bh, Sp, 16 * qt + 4 * g, key), (unsigned long long)Sp, thr, lane) : 15u;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const float p = masked ? 0.f : __builtin_amdgcn_exp2f(s[r] * c2 - l4[r]);
@@ -1885,7 +1906,7 @@ int launch_att_tagged(const AttArgs &a, size_t lds, hipStream_t stream) {
         if (e != hipSuccess) return (int)e;
         if (dev >= 0) done[dev] = true;
     }
-    hipLaunchKernelGGL(kernel, dim3(a.B * a.h), dim3(kAttThreads), lds, stream, a);
+    hipLaunchKernelGGL(kernel, dim3(att_grid(a.B, a.h)), dim3(kAttThreads), lds, stream, a);
     return status();
 }
 template <bool BWD>
@@ -2131,7 +2152,7 @@ int ltr_enc_ffn_bwd_w(const uint16_t *n2, const uint16_t *w1, const float *b1, c
     if (nsplit < 1 || nsplit > 1024) return LTR_ERR_SHAPE;
     FfnArgs a{n2, w1, w2, dy, b1, nullptr, nullptr, (long long)T, dff, drop_p, (unsigned long long)seed, stream_hidden, 0, nullptr,
               dw1_parts, dw2_parts, db1_parts, nsplit};
-    const dim3 grid((unsigned)(dff / kFfnChunk), (unsigned)nsplit);
+    const dim3 grid((unsigned)((nsplit + 7) / 8 * 8 * (dff / kFfnChunk)));
     static bool d64[64] = {}, d128[64] = {};
     if (d == 64) return ffn_launch(ffn_bwd_w_kernel<64>, d64, grid, 2 * 2 * 128 * (64 + 16) * sizeof(bf16_t), a, (hipStream_t)stream);
     return ffn_launch(ffn_bwd_w_kernel<128>, d128, grid, (2 * 128 * (128 + 16) + 2 * 128 * 128) * sizeof(bf16_t), a, (hipStream_t)stream);
