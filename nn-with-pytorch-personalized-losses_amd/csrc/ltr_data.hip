@@ -108,36 +108,80 @@ struct ScanResult {
     int err = 0;
 };
 
-// Parse one line.  X == nullptr: scan only (feature-id range).  Returns 0, or LTR_ERR_PARSE.
+// Bounded numeric parsing: the mapping is NOT NUL-terminated and strtod/strtol skip '\n' as white space, so every token
+// is delimited first ([s, t): up to the next blank / '#' / ':' / line end e), copied into a NUL-terminated stack buffer
+// and must be consumed ENTIRELY by the conversion.  Empty values ("2:" at a line end), over-long tokens and non-finite
+// values (nan, inf, 1e400) are parse errors, as is anything that would read past the line.
+inline const char *token_end(const char *s, const char *e, bool stop_at_colon) {
+    while (s < e && *s != ' ' && *s != '\t' && *s != '\r' && *s != '\n' && *s != '#' && !(stop_at_colon && *s == ':')) ++s;
+    return s;
+}
+
+inline bool parse_f64(const char *s, const char *t, double *out) {
+    char buf[64];
+    const size_t n = (size_t)(t - s);
+    if (n == 0 || n >= sizeof(buf)) return false;
+    memcpy(buf, s, n);
+    buf[n] = 0;
+    char *q = nullptr;
+    const double v = strtod(buf, &q);
+    if (q != buf + n || !(v - v == 0.0)) return false;        // whole token consumed; finite
+    if (buf[0] == ' ' || buf[0] == '\t') return false;
+    *out = v;
+    return true;
+}
+
+inline bool parse_i64(const char *s, const char *t, long long *out) {
+    if (s >= t || t - s > 19) return false;
+    bool neg = false;
+    if (*s == '-' || *s == '+') {
+        neg = *s == '-';
+        if (++s >= t) return false;
+    }
+    long long v = 0;
+    for (; s < t; ++s) {
+        if (*s < '0' || *s > '9') return false;
+        v = v * 10 + (*s - '0');
+    }
+    *out = neg ? -v : v;
+    return true;
+}
+
+// Parse one line [s, e) (e = the '\n' or the end of the mapping; never dereferenced).  X == nullptr: scan only
+// (feature-id range).  Returns 0, or LTR_ERR_PARSE.
 inline int parse_line(const char *s, const char *e, int n_features, int fid_base, float *X, double *y, int64_t *qid,
                       int32_t *min_fid, int32_t *max_fid) {
-    char *q = nullptr;
-    const double label = strtod(s, &q);
-    if (q == s) return LTR_ERR_PARSE;
+    while (s < e && (*s == ' ' || *s == '\t')) ++s;
+    const char *t = token_end(s, e, false);
+    double label;
+    if (!parse_f64(s, t, &label)) return LTR_ERR_PARSE;
     if (y) *y = label;
-    s = q;
+    s = t;
     if (qid) *qid = -1;
     while (s < e) {
         while (s < e && (*s == ' ' || *s == '\t' || *s == '\r')) ++s;
         if (s >= e || *s == '#') break;
         if (e - s > 4 && s[0] == 'q' && s[1] == 'i' && s[2] == 'd' && s[3] == ':') {
-            const long long v = strtoll(s + 4, &q, 10);
-            if (q == s + 4) return LTR_ERR_PARSE;
+            t = token_end(s + 4, e, false);
+            long long v;
+            if (!parse_i64(s + 4, t, &v)) return LTR_ERR_PARSE;
             if (qid) *qid = (int64_t)v;
-            s = q;
+            s = t;
             continue;
         }
-        const long fid = strtol(s, &q, 10);
-        if (q == s || q >= e || *q != ':') return LTR_ERR_PARSE;
-        s = q + 1;
-        const double v = strtod(s, &q);
-        if (q == s) return LTR_ERR_PARSE;
-        s = q;
-        if (fid < 0) return LTR_ERR_PARSE;
+        t = token_end(s, e, true);
+        long long fid;
+        if (t >= e || *t != ':' || !parse_i64(s, t, &fid)) return LTR_ERR_PARSE;
+        s = t + 1;
+        t = token_end(s, e, false);
+        double v;
+        if (!parse_f64(s, t, &v)) return LTR_ERR_PARSE;           // "k:" with nothing behind it is an error, like sklearn
+        s = t;
+        if (fid < 0 || fid > 0x7ffffff0) return LTR_ERR_PARSE;
         if (min_fid && (int32_t)fid < *min_fid) *min_fid = (int32_t)fid;
         if (max_fid && (int32_t)fid > *max_fid) *max_fid = (int32_t)fid;
         if (X) {
-            const long c = fid - fid_base;
+            const long long c = fid - fid_base;
             if (c < 0 || c >= n_features) return LTR_ERR_PARSE;
             X[c] = (float)v;                     // float64 parse, then the reference's astype(np.float32) (dataset.py:63)
         }

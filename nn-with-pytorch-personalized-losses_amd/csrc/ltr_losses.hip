@@ -47,6 +47,7 @@ inline int allow_lds(K kernel, size_t lds) {
 }
 
 // ------------------------------------------------------------------------------------ approxNDCG
+constexpr int kApproxArrays = 7;  // sc yl gn gg uu mk um
 __global__ void __launch_bounds__(1024)
 approxndcg_kernel(const float *__restrict__ scores, const float *__restrict__ labels, int B, int S, int group,
                   float alpha, float eps, float pad, float gscale, float *__restrict__ slate_loss,
@@ -56,10 +57,13 @@ approxndcg_kernel(const float *__restrict__ scores, const float *__restrict__ la
     const int gid = threadIdx.x / group;
     const int slate = blockIdx.x * (blockDim.x / group) + gid;
     const bool active = slate < B;
-    float *base = smem + (size_t)gid * (6 * s_al + group + 32);
+    float *base = smem + (size_t)gid * (kApproxArrays * s_al + group + 32);
     float *sc = base, *yl = sc + s_al, *gn = yl + s_al, *gg = gn + s_al, *uu = gg + s_al, *mk = uu + s_al;
-    const SlateGroup g = make_group(S, group, mk + s_al);
+    ApproxScratch xs;
+    xs.um = mk + s_al;
+    const SlateGroup g = make_group(S, group, xs.um + s_al);
     const size_t off = (size_t)slate * S;
+    approx_ndcg_init(g);
     for (int j = g.t; j < S; j += group) {
         const float y = active ? labels[off + j] : pad;
         sc[j] = active ? scores[off + j] : 0.f;
@@ -68,7 +72,7 @@ approxndcg_kernel(const float *__restrict__ scores, const float *__restrict__ la
     __syncthreads();
     float *dst = dscores ? dscores + off : nullptr;
     const float loss = approx_ndcg_slate(g, sc, yl, gn, gg, uu, mk, alpha, eps, gscale, dscores != nullptr,
-                                         [&](int i, float v) { if (active) dst[i] = v; });
+                                         [&](int i, float v) { if (active) dst[i] = v; }, NoStamp(), xs);
     if (active && g.t == 0) slate_loss[slate] = loss;
 }
 
@@ -471,7 +475,7 @@ int ltr_approxndcg_fwd_bwd(const float *scores, const float *labels, int B, int 
                            float pad, float grad_scale, float *slate_loss, float *dscores, void *stream) {
     if (int rc = check_slates(scores, labels, slate_loss, B, S)) return rc;
     if (B == 0) return LTR_OK;
-    const SlateLaunch L = plan(B, S, 6);
+    const SlateLaunch L = plan(B, S, kApproxArrays);
     if (int rc = allow_lds(approxndcg_kernel, L.lds)) return rc;
     hipLaunchKernelGGL(approxndcg_kernel, dim3(L.grid), dim3(L.block), L.lds, (hipStream_t)stream, scores, labels,
                        B, S, L.group, alpha, eps, pad, grad_scale, slate_loss, dscores);

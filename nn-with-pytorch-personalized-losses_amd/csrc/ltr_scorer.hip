@@ -519,7 +519,7 @@ __global__ void __launch_bounds__(kThreads, 2) slate_pipeline_kernel(const PipeA
     float *dsc = gg + kTileDocs;              // [128] d loss / d score
     float *uu = dsc + kTileDocs;              // [128] loss scratch (per-document exponentials)
     float *mk = uu + kTileDocs;               // [128] loss scratch (valid-document mask)
-    float *xt = mk + kTileDocs;               // [128] loss scratch (LambdaLoss ranks)
+    float *xt = mk + kTileDocs;               // [128] loss scratch (LambdaLoss ranks; approxNDCG: masked exponentials)
     float *w3s = xt + kTileDocs;              // [NT2*16 + 16] w3 (zero padded), b3
     float *dw3 = w3s + N::NT2 * 16 + 16;      // [kWaves][NT2*16] per-wave dw3 accumulators
     float *scratch = dw3 + kWaves * N::NT2 * 16;   // [512 + 4*32] slate-group scratch
@@ -541,6 +541,7 @@ __global__ void __launch_bounds__(kThreads, 2) slate_pipeline_kernel(const PipeA
 #endif
     for (int j = tid; j < N::NT2 * 16 + 16; j += kThreads) w3s[j] = a.packed[N::W3_OFF + j];
     for (int j = tid; j < kWaves * N::NT2 * 16; j += kThreads) dw3[j] = 0.f;
+    for (int j = tid; j < kThreads + 4 * 32; j += kThreads) scratch[j] = 0.f;   // incl. the label bins of approx_ndcg_slate
     float db3 = 0.f;
     f32x4 accW1[N::TW1], accW2[N::TW2];
     if (MODE != MODE_FWD) {
@@ -695,15 +696,17 @@ __global__ void __launch_bounds__(kThreads, 2) slate_pipeline_kernel(const PipeA
                 auto st_ds = [&](int i, float v) { dsc[so + i] = v; };
                 // group = 4 S -> 4 column groups per row: block length S / 4, known at compile time per branch
                 auto stamp_fn = [&](int k) { LTR_STAMP(k) };
+                ApproxScratch xs;               // enables the no-clamp path (4 pair terms per v_rcp, histogram ideal DCG)
+                xs.um = xt + so;
                 if (a.S == 128)
                     loss = approx_ndcg_slate<32>(g, sc + so, yl + so, gn + so, gg + so, uu + so, mk + so, a.alpha,
-                                                 a.eps, a.gscale, true, st_ds, stamp_fn);
+                                                 a.eps, a.gscale, true, st_ds, stamp_fn, xs);
                 else if (a.S == 64)
                     loss = approx_ndcg_slate<16>(g, sc + so, yl + so, gn + so, gg + so, uu + so, mk + so, a.alpha,
-                                                 a.eps, a.gscale, true, st_ds);
+                                                 a.eps, a.gscale, true, st_ds, NoStamp(), xs);
                 else
                     loss = approx_ndcg_slate<8>(g, sc + so, yl + so, gn + so, gg + so, uu + so, mk + so, a.alpha,
-                                                a.eps, a.gscale, true, st_ds);
+                                                a.eps, a.gscale, true, st_ds, NoStamp(), xs);
             }
             else if (LOSS == 1)
                 loss = listnet_slate(g, yl + so, sc + so, a.apply_sigmoid != 0, a.gscale, true,

@@ -58,46 +58,96 @@ __device__ __forceinline__ float ideal_dcg(const SlateGroup &g, const float *yl,
 //     u_k = exp(alpha (s_k - mid)),   sigmoid(-alpha (s_i - s_j)) = u_j / (u_i + u_j),
 // i.e. one v_rcp per pair and no v_exp.  Wider ranges (where u would leave fp32) take the per-pair exp path.
 typedef float lds_f4 __attribute__((ext_vector_type(4)));
+typedef float lds_f2 __attribute__((ext_vector_type(2)));
 
 struct NoStamp {
     __device__ __forceinline__ void operator()(int) const {}
 };
 
+// Optional extra LDS scratch that enables the NO-CLAMP path of approx_ndcg_slate (s_al floats):
+//   um[j] = u_j for real documents, 0 for padded ones (the numerators).
+// Contract: the 32 integer label bins  (int *)(g.part + 32)  are ZERO on entry (approx_ndcg_init before a barrier
+// ahead of the first call; the function re-zeroes them before it returns).
+struct ApproxScratch {
+    float *um = nullptr;
+};
+
+__device__ __forceinline__ void approx_ndcg_init(const SlateGroup &g) {
+    if (g.t < 32) reinterpret_cast<int *>(g.part + 32)[g.t] = 0;
+}
+
+// No-clamp path ("ultra"), taken per slate when
+//   (a) every |alpha (s_k - s_0)| <= 8   -> u in [3.4e-4, 2981]: products of up to eight (u_i + u_j) stay inside fp32, and
+//       every pair sigmoid is >= sigmoid(-16) = 1.1e-7 >= eps, so no max(., eps) clamp of approxNDCG.py:49 is active;
+//   (b) every clamped label max(y, 0) is an integer <= 15 (graded relevance; gains <= 32767 keep the batched products in range) -> the ideal DCG comes from a 32-bin
+//       histogram (LDS integer adds: exact, order-free) instead of an S^2 rank count.
+// Then FOUR pair terms share ONE v_rcp_f32:
+//   sum_k n_k / d_k  (k = 0..3)  =  (N01 D23 + N23 D01) / (D01 D23),   N01 = n0 d1 + n1 d0,  D01 = d0 d1, ...
+// which the compiler maps onto packed fp32 (v_pk_mul/add/fma_f32): 3.3 issue slots per ordered pair in sweep 1
+// (was ~13: add, rcp = 4 slots, mul, max, fma and 5 of rank counting) and 4.3 in sweep 2 (was ~14).
+// sweep 1:  pos_i - 1 = sum_j um_j / (u_i + u_j) - 1/2 [i real]
+// sweep 2:  d loss / d s_k = alpha u_k sum_j um_j (g_j - g_k) / (u_k + u_j)^2        (t_kj = u_k u_j / (u_k + u_j)^2)
 template <int JB = 0, class Store, class Stamp = NoStamp>
 __device__ __forceinline__ float approx_ndcg_slate(const SlateGroup &g, float *sc, float *yl, const float *gn,
                                                    float *gg, float *uu, float *mk, float alpha, float eps,
-                                                   float gscale, bool want_grad, Store store, Stamp stamp = Stamp()) {
+                                                   float gscale, bool want_grad, Store store, Stamp stamp = Stamp(),
+                                                   ApproxScratch xs = ApproxScratch()) {
     const int s_al = (g.S + 3) & ~3;
     // contiguous column block of this column group, multiple of 4
     const int jb = JB > 0 ? JB : ((((g.S + g.CG - 1) / g.CG) + 3) & ~3);
     const int j0 = g.cg * jb;
     const int j1 = JB > 0 ? j0 + JB : min(j0 + jb, s_al);
+    const bool ultra_ok = xs.um != nullptr && eps <= 1e-7f;
+    int *bins = reinterpret_cast<int *>(g.part + 32);
 
     // Per-document exponentials relative to the first document's score.  The fast path is valid while every
-    // |alpha (s_k - s_0)| <= 69 (u in [1e-30, 1e30]: sums and ratios stay in fp32 range); one flag per wave,
-    // combined behind the SAME barrier that publishes uu / mk / gg, decides fast vs slow for the whole slate.
+    // |alpha (s_k - s_0)| <= 69 (u in [1e-30, 1e30]: sums and ratios stay in fp32 range); one flag word per wave,
+    // combined behind the SAME barrier that publishes uu / mk / gg, decides ultra vs fast vs slow for the whole slate.
     const float sref = alpha * sc[0];
-    bool bad = false;
+    bool bad = false, noultra = false;
+    float ymax = 0.f;
     for (int j = g.t; j < s_al; j += g.group) {
         const bool real = j < g.S && gn[j] >= 0.f;
         const float x = real ? alpha * sc[j] - sref : 0.f;
         bad = bad || !(fabsf(x) <= 69.f);          // NaN scores take the slow path too
+        const float u = real ? expf(x) : 1.f;
         mk[j] = real ? 1.f : 0.f;
-        uu[j] = real ? expf(x) : 1.f;
+        uu[j] = u;
+        if (ultra_ok) {
+            noultra = noultra || !(fabsf(x) <= 8.f);
+            xs.um[j] = real ? u : 0.f;
+            if (real) {
+                const float yc = fmaxf(yl[j], 0.f);
+                const bool isint = yc <= 15.f && yc == floorf(yc);
+                noultra = noultra || !isint;
+                ymax = fmaxf(ymax, isint ? yc : 0.f);
+                if (isint) __hip_atomic_fetch_add(&bins[(int)yc], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+        }
         if (j >= g.S) {
             sc[j] = 0.f;
             yl[j] = -INFINITY;
         }
         gg[j] = 0.f;
     }
-    if ((threadIdx.x & (LTR_WAVE - 1)) == 0) g.part[g.wig] = 0.f;
-    __builtin_amdgcn_wave_barrier();
-    if (bad) g.part[g.wig] = 1.f;                   // benign same-value race inside one wave
+    {
+        const float fl = (__ballot(bad) ? 2.f : 0.f) + ((!ultra_ok || __ballot(noultra)) ? 1.f : 0.f);
+        const float ym = ultra_ok ? wave_allmax(ymax) : 0.f;
+        if ((threadIdx.x & (LTR_WAVE - 1)) == 0) {
+            g.part[g.wig] = fl;
+            g.part[16 + g.wig] = ym;
+        }
+    }
     __syncthreads();
     stamp(10);
-    float nbad = 0.f;
-    for (int w = 0; w < g.nw; ++w) nbad += g.part[w];
-    const bool fast = nbad == 0.f;
+    bool fast = true, ultra = ultra_ok;
+    int ytop = 0;
+    for (int w = 0; w < g.nw; ++w) {
+        const float fl = g.part[w];
+        fast = fast && fl < 2.f;
+        ultra = ultra && fl == 0.f;
+        ytop = max(ytop, (int)g.part[16 + w]);
+    }
     stamp(11);
 
     // One sweep per row: label rank by counting (ideal DCG term, approxNDCG.py:28,43) and the soft rank
@@ -108,6 +158,38 @@ __device__ __forceinline__ float approx_ndcg_slate(const SlateGroup &g, float *s
         const bool row = i < g.S;
         const bool vi = row && gn[i] >= 0.f;
         float p = 0.f, cnt = 0.f;
+        if (ultra) {
+            if (vi) {
+                const float ui = uu[i];
+                lds_f2 acc = {0.f, 0.f};
+#pragma unroll 2
+                for (int j = j0; j < j1; j += 4) {
+                    const lds_f4 u = *reinterpret_cast<const lds_f4 *>(uu + j);
+                    const lds_f4 n = *reinterpret_cast<const lds_f4 *>(xs.um + j);
+                    const lds_f2 da = {ui + u[0], ui + u[2]}, db = {ui + u[1], ui + u[3]};      // (d0,d2) (d1,d3)
+                    const lds_f2 na = {n[0], n[2]}, nb = {n[1], n[3]};
+                    const lds_f2 D = da * db;                                                    // (D01, D23)
+                    const lds_f2 N = na * db + nb * da;                                          // (N01, N23)
+                    const float den = D[0] * D[1];
+                    const float num = fmaf(N[0], D[1], N[1] * D[0]);
+                    acc[(j >> 2) & 1] = fmaf(num, __frcp_rn(den), acc[(j >> 2) & 1]);
+                }
+                p = acc[0] + acc[1];
+                if (i >= j0 && i < j1) p -= 0.5f;                                               // the j == i term: u_i / (2 u_i)
+            }
+            // ideal-DCG term of RANK i from the label histogram: the document at sorted position i has the label v with
+            // (#labels > v) <= i < (#labels >= v); labels 0 carry no gain
+            if (row && g.cg == 0) {
+                int cum = 0;
+                float gr = 0.f;
+                for (int v = ytop; v >= 1; --v) {
+                    const int c = bins[v];
+                    gr = (i >= cum && i < cum + c) ? exp2f((float)v) - 1.f : gr;
+                    cum += c;
+                }
+                cnt = gr;                                                                        // gain at sorted rank i
+            }
+        } else {
         if (row) {
             const float yi = yl[i];
             float c0 = 0.f, c1 = 0.f, c2 = 0.f, c3 = 0.f;
@@ -145,14 +227,17 @@ __device__ __forceinline__ float approx_ndcg_slate(const SlateGroup &g, float *s
                 }
             }
         }
-        const float r = row_reduce(g, cnt);
+        }
+        const float r = ultra ? 0.f : row_reduce(g, cnt);
         const float pos = 1.f + row_reduce(g, p);
+        if (ultra && row && g.cg == 0 && cnt > 0.f) idcg_acc += cnt / log2f(2.f + (float)i);
         if (vi && g.cg == 0) {
             const float gain = gn[i];
             const float L = log2f(1.f + pos);
-            if (gain > 0.f) idcg_acc += gain / log2f(2.f + r);
+            if (!ultra && gain > 0.f) idcg_acc += gain / log2f(2.f + r);
             loss_acc += gain / L;
-            gg[i] = gain / (L * L * (1.f + pos) * LTR_LN2);      // d(-sum gain/L)/d pos_i, not yet / maxDCG
+            const float gi = gain / (L * L * (1.f + pos) * LTR_LN2);   // d(-sum gain/L)/d pos_i, not yet / maxDCG
+            gg[i] = gi;
         }
     }
     stamp(12);
@@ -164,6 +249,7 @@ __device__ __forceinline__ float approx_ndcg_slate(const SlateGroup &g, float *s
         g.red[2 * g.wig + 1] = loss_acc;
     }
     __syncthreads();
+    if (ultra_ok && g.t < 32) bins[g.t] = 0;                    // every reader of the histogram is past the barrier
     idcg_acc = 0.f;
     loss_acc = 0.f;
     for (int w = 0; w < g.nw; ++w) {
@@ -182,7 +268,27 @@ __device__ __forceinline__ float approx_ndcg_slate(const SlateGroup &g, float *s
         const bool row = k < g.S;
         const bool vk = row && gn[k] >= 0.f;
         float a = 0.f;
-        if (vk) {
+        if (vk && ultra) {
+            const float gk = gg[k], uk = uu[k];
+            lds_f2 acc = {0.f, 0.f};
+#pragma unroll 2
+            for (int j = j0; j < j1; j += 4) {
+                const lds_f4 u = *reinterpret_cast<const lds_f4 *>(uu + j);
+                const lds_f4 n = *reinterpret_cast<const lds_f4 *>(xs.um + j);
+                const lds_f4 gj = *reinterpret_cast<const lds_f4 *>(gg + j);
+                lds_f2 da = {uk + u[0], uk + u[2]}, db = {uk + u[1], uk + u[3]};
+                da = da * da;                                                                    // (q0, q2)
+                db = db * db;                                                                    // (q1, q3)
+                const lds_f2 ta = lds_f2{n[0], n[2]} * (lds_f2{gj[0], gj[2]} - gk);             // (t0, t2); exactly 0 at j == k
+                const lds_f2 tb = lds_f2{n[1], n[3]} * (lds_f2{gj[1], gj[3]} - gk);             // (t1, t3)
+                const lds_f2 Q = da * db;                                                        // (Q01, Q23)
+                const lds_f2 N = ta * db + tb * da;                                              // (N01, N23)
+                const float den = Q[0] * Q[1];
+                const float num = fmaf(N[0], Q[1], N[1] * Q[0]);
+                acc[(j >> 2) & 1] = fmaf(num, __frcp_rn(den), acc[(j >> 2) & 1]);
+            }
+            a = uk * (acc[0] + acc[1]);
+        } else if (vk) {
             const float gk = gg[k];
             if (fast) {
                 const float uk = uu[k];

@@ -4,8 +4,10 @@ Slates are independent, so the path shards by query with no data-path collective
 single all-reduce(SUM) of ONE flat fp32 buffer [all parameter gradients | loss] (37 402 floats = 150 KB for
 DoubleLayerNet) over RCCL/xGMI (`torch.distributed` backend "nccl" on ROCm).  At this size the collective is
 latency-bound, so it is issued once per step, not bucketed.  Reduction rules:
-approxNDCG is a MEAN over the global batch -> each rank pre-scales by 1/B_global; ListNet is a SUM -> no
-scaling.  Works unchanged on the gloo backend (CPU tests, world_size 2).
+approxNDCG is a MEAN over the global batch -> each rank pre-scales by 1/B_global when the caller knows it, else the
+local batch size rides along in the buffer and the division follows the all-reduce; ListNet / lambdaLoss("sum") are
+SUMs -> no scaling; lambdaLoss("mean") divides by the GLOBAL kept-pair count, all-reduced in the same buffer.
+Works unchanged on the gloo backend (CPU tests, world_size 2).
 """
 import torch
 import torch.distributed as dist
@@ -40,22 +42,30 @@ def sync_parameters(module, src=0, group=None):
 
 class QueryShardedTrainer:
     """local_step: object with `.flat` ([grads | loss] fp32 tensor whose slices alias every param.grad) and
-    `.step(X, y, world_batch=...)` (ltr_mi355x.scorer.FusedRanker on the GPU; any stand-in in tests)."""
+    `.step(X, y, world_batch=...)` (ltr_mi355x.scorer.FusedRanker on the GPU; any stand-in in tests).
 
-    def __init__(self, local_step, optimizer, group=None):
+    Deferred normalisation (local steps that have `.flat_ext`, `.finish_norm()` and `step(defer_norm=True)`): the rank
+    leaves SUM-form contributions in [grads | loss] and appends its normaliser -- its batch size for the batch-mean loss
+    (approxNDCG.py:53), its kept-pair count for lambdaLoss reduction="mean" (lambdaL.py:88-89) -- as one more float of
+    the SAME buffer; after the single all-reduce every rank divides by the global normaliser on the device.  Ragged
+    shards and data-dependent normalisers therefore cost no second collective and no host read."""
+
+    def __init__(self, local_step, optimizer, group=None, always_collective=False):
         self.local = local_step
         self.opt = optimizer
         self.group = group
         self.rank, self.world_size = world()
+        # always_collective: issue the all-reduce even at world_size 1 (exercises the backend on a one-GPU box)
+        self.collective = self.world_size > 1 or (always_collective and dist.is_available() and dist.is_initialized())
+        self.deferred = all(hasattr(local_step, a) for a in ("flat_ext", "finish_norm"))
         # every rank draws its OWN dropout stream: the keep bits are keyed on (seed, local document index), so
         # without a per-rank salt document i of every shard would share one mask (ltr_scorer.hip keep_word)
         if hasattr(self.local, "seed_salt"):
             self.local.seed_salt = self.rank
 
     def global_batch_of(self, b_local, device):
-        """Sum of the ranks' local batch sizes (one 8-byte all-reduce + host read).  `shard_range` shards differ by
-        one slate, so B_local * world_size is wrong for ragged shards; callers with equal shards pass
-        `global_batch` to `step` and skip this collective (bench.py does)."""
+        """Sum of the ranks' local batch sizes (one 8-byte all-reduce + host read): only for local steps WITHOUT the
+        deferred-normalisation protocol."""
         if self.world_size == 1:
             return b_local
         t = torch.tensor([b_local], dtype=torch.int64, device=device)
@@ -64,12 +74,20 @@ class QueryShardedTrainer:
 
     def step(self, X, y, global_batch=None):
         """One optimizer step on this rank's slates.  Returns the GLOBAL loss (0-dim tensor, no host sync).
-        global_batch: total slates over all ranks this step; default = all-reduced sum of the local sizes
-        (every rank must then take the default, or every rank pass the value)."""
-        gb = int(global_batch) if global_batch else self.global_batch_of(int(X.shape[0]), X.device)
-        self.local.step(X, y, world_batch=gb)
-        if self.world_size > 1:
-            dist.all_reduce(self.local.flat, op=dist.ReduceOp.SUM, group=self.group)
+        global_batch: total slates over all ranks this step when the caller knows it (equal shards: bench.py) -- the
+        batch-mean loss is then pre-scaled inside the launch.  Default: deferred normalisation (see the class docstring);
+        every rank must make the same choice."""
+        data_dependent = getattr(self.local, "mean_kind", None) == "pairs"
+        if self.deferred and (global_batch is None or data_dependent):
+            self.local.step(X, y, defer_norm=True)
+            if self.collective:
+                dist.all_reduce(self.local.flat_ext, op=dist.ReduceOp.SUM, group=self.group)
+            self.local.finish_norm()
+        else:
+            gb = int(global_batch) if global_batch else self.global_batch_of(int(X.shape[0]), X.device)
+            self.local.step(X, y, world_batch=gb)
+            if self.collective:
+                dist.all_reduce(self.local.flat, op=dist.ReduceOp.SUM, group=self.group)
         self.opt.step()
         return self.local.flat[-1]
 
@@ -90,24 +108,31 @@ class ModuleShardedTrainer:
             module.ltr_seed = (int(module.ltr_seed) + 0xA24BAED4963EE407 * self.rank) & ((1 << 64) - 1)
         self.params = [p for p in module.parameters() if p.requires_grad]
 
-    def step(self, loss_closure, b_local, global_batch=None):
-        """loss_closure() -> this rank's loss (0-dim, attached to the graph).  Returns the GLOBAL loss (0-dim)."""
+    def step(self, loss_closure, b_local, global_batch=None, weight=None):
+        """loss_closure() -> this rank's loss (0-dim, attached to the graph).  Returns the GLOBAL loss (0-dim).
+        reduction "mean": every rank's gradient and loss are weighted by `weight` (default: its batch size b_local; a
+        0-dim device tensor for data-dependent normalisers such as a kept-pair count) and the weight rides along as the
+        last float of the one all-reduced buffer -- no size collective, no host read."""
         self.opt.zero_grad(set_to_none=True)
         loss = loss_closure()
         loss.backward()
-        dev = loss.device
         if self.world_size > 1:
-            if global_batch:
-                gb = int(global_batch)
-            else:
-                t = torch.tensor([int(b_local)], dtype=torch.int64, device=dev)
-                dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
-                gb = int(t.item())
-            w = float(b_local) / gb if self.reduction == "mean" else 1.0
             dt = torch.float64 if any(p.dtype == torch.float64 for p in self.params) else torch.float32
             flat = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1).to(dt) for p in self.params]
-                             + [loss.detach().reshape(1).to(dt)]) * w
+                             + [loss.detach().reshape(1).to(dt)])
+            if self.reduction == "mean":
+                if weight is None and global_batch:
+                    flat = flat * (float(b_local) / int(global_batch))
+                    w = None
+                else:
+                    w = (weight.detach().reshape(1).to(dt) if torch.is_tensor(weight) else
+                         torch.full((1,), float(b_local if weight is None else weight), dtype=dt, device=flat.device))
+                    flat = torch.cat([flat * w, w])
+            else:
+                w = None
             dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
+            if w is not None:
+                flat = flat[:-1] / flat[-1]
             off = 0
             for p in self.params:
                 g = flat[off:off + p.numel()].view_as(p).to(p.dtype)
@@ -116,6 +141,6 @@ class ModuleShardedTrainer:
                 else:
                     p.grad.copy_(g)
                 off += p.numel()
-            loss = flat[-1]
+            loss = flat[off]
         self.opt.step()
         return loss.detach()

@@ -579,7 +579,9 @@ class EncoderApproxNDCG(torch.autograd.Function):
         st = ctx.st
         with torch.cuda.device(go.device):
             with deferred_reductions():
-                grads = _body_backward(ctx.spec, ctx.seed, st, ctx.dx, ctx.tail)
+                # the backward accumulates into its dx argument in place: hand it a copy, so that a second backward over
+                # the same graph (retain_graph=True / gradient accumulation over one forward) starts from the tail's dx again
+                grads = _body_backward(ctx.spec, ctx.seed, st, ctx.dx.clone(), ctx.tail)
             scale = go.detach().to(torch.float32)
             out = [None if g is None else (g * scale).to(dt).reshape(p.shape) for g, dt, p in zip(grads, ctx.param_dtypes, st["prm"])]
         return (None, None, None, None, None, None, None, None, None, *out)

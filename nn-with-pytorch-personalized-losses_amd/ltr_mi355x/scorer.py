@@ -208,9 +208,15 @@ class FusedRanker:
         dev = self.params[0].device
         self.device = dev
         self.grid = int(grid) if grid else cu_count(dev)
-        # one flat fp32 buffer [all parameter gradients | loss]: the ONLY thing data parallel all-reduces
-        self.flat = torch.zeros(self.info.n_params + 1, dtype=torch.float32, device=dev)
+        # one flat fp32 buffer [all parameter gradients | loss | normaliser]: the ONLY thing data parallel all-reduces.
+        # `flat` = [grads | loss] (what the optimizer and callers read); `flat_ext` adds the normaliser slot of the
+        # deferred-normalisation protocol (step(defer_norm=True) -> all-reduce(flat_ext) -> finish_norm()): the local
+        # batch size for the batch-mean loss (approxNDCG.py:53), the local kept-pair count for lambdaLoss
+        # reduction="mean" (lambdaL.py:88-89) -- so the GLOBAL mean needs neither a second collective nor a host sync.
+        self.flat_ext = torch.zeros(self.info.n_params + 2, dtype=torch.float32, device=dev)
+        self.flat = self.flat_ext[:self.info.n_params + 1]
         self.flat_grad = self.flat[:self.info.n_params]
+        self._norm = self.flat_ext[self.info.n_params + 1:]          # 1-element view
         self._grad_views = []
         off = 0
         for p in self.params:           # every p.grad is a view into the flat buffer
@@ -235,9 +241,29 @@ class FusedRanker:
             if p.grad is not v:
                 p.grad = v
 
-    def step(self, X, y, world_batch=None, keep1=None, keep2=None, seed=None, train=None):
+    @property
+    def mean_kind(self):
+        """How the loss normalises: "batch" (approxNDCG: mean over slates), "pairs" (lambdaLoss reduction="mean": mean
+        over kept pairs -- data dependent), None (plain sums: ListNet, lambdaLoss "sum")."""
+        if self.loss_kind == LOSS_APPROXNDCG:
+            return "batch"
+        if self.loss_kind == LOSS_LAMBDA and self.reduction == "mean":
+            return "pairs"
+        return None
+
+    def finish_norm(self):
+        """Second half of the deferred-normalisation protocol: divide [grads | loss] by the (all-reduced) normaliser.
+        Device ops only.  0 / 0 = nan is the reference's "mean of nothing"."""
+        if self.mean_kind is not None:
+            self.flat.div_(self._norm)
+        self._bind_grads()
+        return self._loss_out
+
+    def step(self, X, y, world_batch=None, keep1=None, keep2=None, seed=None, train=None, defer_norm=False):
         """Run the fused pass on this rank's slates.  Returns the 0-dim LOCAL loss contribution, already
-        scaled for the global batch (sum over ranks == the reference's loss on the global batch)."""
+        scaled for the global batch (sum over ranks == the reference's loss on the global batch).
+        defer_norm=True: leave SUM-form contributions in `flat` and this rank's normaliser in `flat_ext[-1]`; the caller
+        all-reduces `flat_ext` and calls `finish_norm()` (ltr_mi355x.dp.QueryShardedTrainer)."""
         info = self.info
         require_device(X, y)
         if X.dim() != 3 or X.shape[2] != info.F or tuple(y.shape[:2]) != tuple(X.shape[:2]):
@@ -246,30 +272,34 @@ class FusedRanker:
         if S < 1 or S > 2048:
             raise ValueError(f"slate_length {S} outside the supported range 1..2048")
         lambda_mean = self.loss_kind == LOSS_LAMBDA and self.reduction == "mean"
-        if lambda_mean and world_batch not in (None, B):
-            raise NotImplementedError('lambdaLoss reduction="mean" divides by the GLOBAL kept-pair count; '
-                                      "under data parallel use reduction=\"sum\" (the reference default)")
+        if lambda_mean and not defer_norm and world_batch not in (None, B):
+            raise ValueError('lambdaLoss reduction="mean" divides by the GLOBAL kept-pair count, which no rank knows before '
+                             "the all-reduce: under data parallel call step(defer_norm=True) (QueryShardedTrainer does)")
         # one launch when the slate tiles a 128-document super-tile; otherwise forward launch + loss kernel +
-        # backward launch (X read twice, forward recomputed) -- same flat gradient buffer either way
-        one_launch = S in (32, 64, 128) and not lambda_mean
+        # backward launch -- same flat gradient buffer either way
+        one_launch = S in (32, 64, 128)
         if B == 0:
             # no slates on this rank: zero gradient contribution; the loss of an empty batch is what the
             # reference's reduction gives (mean of nothing = nan, sum of nothing = 0) unless a global batch is set
-            self.flat.zero_()
-            if self.loss_kind == LOSS_APPROXNDCG and not world_batch:
+            self.flat_ext.zero_()
+            if self.loss_kind == LOSS_APPROXNDCG and not world_batch and not defer_norm:
                 self.flat[self.info.n_params] = float("nan")
             self._bind_grads()
             return self._loss_out
         if self.loss_kind == LOSS_LAMBDA and self.lambda_args[1] < 0:
             # k = 0: `ndcg_at_k_mask[:0, :0]` keeps no pair (lambdaL.py:29-30) -> loss 0 ("sum") / nan ("mean" of
             # nothing), zero gradient, for every slate length
-            self.flat.zero_()
-            if lambda_mean:
+            self.flat_ext.zero_()
+            if lambda_mean and not defer_norm:
                 self.flat[self.info.n_params] = float("nan")
             self._bind_grads()
             return self._loss_out
         gb = int(world_batch) if world_batch else B
-        scale = 1.0 / gb if self.loss_kind == LOSS_APPROXNDCG else 1.0     # mean (approxNDCG.py:53) vs sum (listnet.py:16)
+        # mean over the batch (approxNDCG.py:53) vs sum (listnet.py:16); deferred: sums now, one division after the all-reduce
+        scale = 1.0 / gb if (self.loss_kind == LOSS_APPROXNDCG and not defer_norm) else 1.0
+        if defer_norm and self.loss_kind == LOSS_APPROXNDCG:
+            self._norm.fill_(float(B))
+        count = None
         train = self.module.training if train is None else train
         dropout = bool(train and self.module._ltr_dropout)
         if seed is None:
@@ -284,16 +314,19 @@ class FusedRanker:
             pack_params(self.net, self.params, out=self.packed)
             h = lib()
             if not one_launch:
-                out = self._step_three_launches(h, x2, yy, B, S, dropout, int(seed) & _MASK64, k1, k2, scale, lambda_mean)
+                out = self._step_three_launches(h, x2, yy, B, S, dropout, int(seed) & _MASK64, k1, k2, scale, lambda_mean,
+                                                defer_norm)
                 self._bind_grads()
                 return out
             if self.kernel_events is not None:
                 self.kernel_events[0].record()
             if self.loss_kind == LOSS_LAMBDA:
                 sid, kk, sigma, mu, eps, pad, lb = self.lambda_args
+                if lambda_mean:
+                    count = torch.empty(B, dtype=torch.float32, device=self.device)
                 check(h.ltr_fused_step_lambda(self.net, _ptr(x2), _ptr(yy), B, S, _ptr(self.packed), int(dropout),
                                               int(seed) & _MASK64, _ptr(k1), _ptr(k2), sid, kk, sigma, mu, eps, pad,
-                                              lb, 1.0, _ptr(self._slate), None, _ptr(self.partials), self.grid,
+                                              lb, 1.0, _ptr(self._slate), _ptr(count), _ptr(self.partials), self.grid,
                                               _stream()), "ltr_fused_step_lambda")
             else:
                 check(h.ltr_fused_step(self.net, self.loss_kind, _ptr(x2), _ptr(yy), B, S, _ptr(self.packed),
@@ -306,10 +339,16 @@ class FusedRanker:
                   "ltr_mlp_reduce_grads")
             check(h.ltr_reduce_sum_f32(_ptr(self._slate), B, scale, self.flat.data_ptr() + 4 * self.info.n_params,
                                        _stream()), "ltr_reduce_sum_f32")
+            if lambda_mean:
+                # the pair-mean is linear in d loss / d scores: the launch ran in sum form, one division of
+                # [grads | loss] by the kept-pair count follows (here, or after the all-reduce when deferred)
+                torch.sum(count, dim=0, keepdim=True, out=self._norm)
+                if not defer_norm:
+                    self.flat.div_(self._norm)
         self._bind_grads()
         return self._loss_out
 
-    def _step_three_launches(self, h, x2, yy, B, S, dropout, seed, k1, k2, scale, lambda_mean):
+    def _step_three_launches(self, h, x2, yy, B, S, dropout, seed, k1, k2, scale, lambda_mean, defer_norm=False):
         """Any slate length (and lambdaLoss "mean"): scorer forward launch -> loss kernel (forward + dL/dscores)
         -> scorer backward launch (recomputes the forward from X with the same dropout stream)."""
         n = B * S
@@ -329,8 +368,6 @@ class FusedRanker:
             count = torch.empty(B, dtype=torch.float32, device=dev)
             check(h.ltr_lambda_fwd_bwd(_ptr(scores), _ptr(yy), B, S, sid, kk, sigma, mu, eps, pad, lb, 1.0,
                                        _ptr(self._slate), _ptr(count), _ptr(ds), _stream()), "ltr_lambda_fwd_bwd")
-            if lambda_mean:
-                ds = ds / count.sum()
         if self.kernel_events is not None:
             self.kernel_events[0].record()
         check(h.ltr_mlp_backward(self.net, _ptr(x2), n, _ptr(self.packed), int(dropout), seed, _ptr(k1), _ptr(k2),
@@ -342,5 +379,7 @@ class FusedRanker:
         check(h.ltr_reduce_sum_f32(_ptr(self._slate), B, scale, self.flat.data_ptr() + 4 * self.info.n_params,
                                    _stream()), "ltr_reduce_sum_f32")
         if lambda_mean:
-            self._loss_out /= count.sum()
+            torch.sum(count, dim=0, keepdim=True, out=self._norm)
+            if not defer_norm:
+                self.flat.div_(self._norm)
         return self._loss_out

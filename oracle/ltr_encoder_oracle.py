@@ -31,6 +31,63 @@ def _rb(x, on):
     return _RoundBf16.apply(x) if on else x
 
 
+def _bf(x):
+    return x.to(torch.bfloat16).to(x.dtype)
+
+
+class _RoundGradBf16(torch.autograd.Function):
+    """Identity whose BACKWARD rounds the gradient to bf16: placed where the HIP backward hands a gradient to the next
+    kernel as bf16 (ltr_mi355x/encoder.py _body_backward: dy after the residual-branch dropout, dz1, dctx, dqkv)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        return _bf(g)
+
+
+def _rg(x, on):
+    return _RoundGradBf16.apply(x) if on else x
+
+
+class _AttnCoreRounded(torch.autograd.Function):
+    """softmax(q k^T / sqrt(dk) + mask) -> dropout -> @ v with the arithmetic of csrc/ltr_encoder.hip
+    attention_fwd_kernel / attention_bwd_kernel: q, k, v, dO arrive as bf16 values; P is computed unrounded, Pd = drop(P)
+    is rounded to bf16 before Pd @ v (and before dV = Pd^T dO); the backward uses D = dO . O with the ROUNDED saved
+    output, dS = P ((keep ? dPd / (1-p) : 0) - D) / sqrt(dk) rounded to bf16 before dQ = dS k and dK = dS^T q."""
+
+    @staticmethod
+    def forward(ctx, q, k, v, pad, keep, p):
+        dk = q.shape[-1]
+        sc = (q @ k.transpose(-2, -1)) / math.sqrt(dk)
+        sc = sc.masked_fill(pad, float("-inf"))
+        P = torch.softmax(sc, dim=-1)
+        P = torch.where(torch.isnan(P), torch.zeros_like(P), P)      # a slate without any unmasked key: zeros (kernel: l = 0)
+        ks = 1.0 / (1.0 - p) if keep is not None and p > 0 else 1.0
+        Pd = _bf(P * keep.to(P.dtype) * ks) if ks != 1.0 else _bf(P)
+        O = _bf(Pd @ v)
+        ctx.save_for_backward(q, k, v, P, Pd, O, keep if keep is not None else torch.ones((), dtype=torch.bool))
+        ctx.ks, ctx.has_keep = ks, ks != 1.0
+        return O
+
+    @staticmethod
+    def backward(ctx, dO):
+        q, k, v, P, Pd, O, keep = ctx.saved_tensors
+        dk = q.shape[-1]
+        scale = 1.0 / math.sqrt(dk)
+        dO = _bf(dO)
+        D = (dO * O).sum(-1, keepdim=True)
+        dPd = dO @ v.transpose(-2, -1)
+        dP = dPd * keep.to(dPd.dtype) * ctx.ks if ctx.has_keep else dPd
+        dS = _bf(P * (dP - D) * scale)
+        dq = dS @ k
+        dk_ = dS.transpose(-2, -1) @ q
+        dv = Pd.transpose(-2, -1) @ dO
+        return dq, dk_, dv, None, None, None
+
+
 def layer_norm_annotated(x, a, b, eps=1e-6):
     """transformer.py:86-88: unbiased std, eps added to the std."""
     mean = x.mean(-1, keepdim=True)
@@ -45,22 +102,27 @@ def _drop(x, keep, p):
     return x * keep.to(x.dtype) / (1.0 - p)
 
 
-def encoder_scores(sd, x, mask, cfg, keep=None, bf16=False):
+def encoder_scores(sd, x, mask, cfg, keep=None, bf16=False, round_bwd=False):
     """Scores [B, S] of a `make_model` network.
       sd    {state_dict key: tensor} (reference key names)
       x     [B, S, F];  mask [B, S] (1 / True = padded) or None when there is no encoder
       cfg   dict(n_fc, input_norm, fc_dropout, n_layers, heads, enc_dropout, has_encoder)
       keep  None (eval) or {site: mask}: ("fc", i) -> [B*S, out_i]; ("attn", l) -> [B, h, S, S];
             ("attn_out", l), ("ffn_out", l) -> [B*S, d];  ("ffn_hidden", l) -> [B*S, d_ff]
+      bf16       round where the HIP FORWARD rounds (operands of every GEMM, saved activations, P, ctx)
+      round_bwd  (with bf16) also round where the HIP BACKWARD rounds: the gradient entering every weight-gradient /
+                 input-gradient GEMM (dy behind the residual-branch dropout, dz1 behind the ReLU gate, dctx, dqkv) and the
+                 attention core's dS, D = dO . O -- so that what is left between kernels and oracle is summation order
     """
     keep = keep or {}
+    rbw = bool(bf16 and round_bwd)
     B, S, F = x.shape
     y = x
     if cfg.get("input_norm"):
         y = torch.nn.functional.layer_norm(y, (F,), sd["input_layer.input_norm.weight"], sd["input_layer.input_norm.bias"], 1e-5)
     for i in range(cfg["n_fc"]):                                      # multiLayer.py:48-50 (activation = Identity)
         W, b = sd[f"input_layer.layers.{i}.weight"], sd[f"input_layer.layers.{i}.bias"]
-        y = _rb(y, bf16) @ _rb(W, bf16).t() + b
+        y = _rg(_rb(y, bf16) @ _rb(W, bf16).t() + b, rbw)
         k = keep.get(("fc", i))
         y = _drop(y, None if k is None else k.view(B, S, -1), cfg["fc_dropout"])
     if cfg["has_encoder"]:
@@ -72,21 +134,26 @@ def encoder_scores(sd, x, mask, cfg, keep=None, bf16=False):
         for l in range(cfg["n_layers"]):
             pre = f"encoder.layers.{l}."
             n1 = _rb(layer_norm_annotated(y, sd[pre + "sublayer.0.norm.a_2"], sd[pre + "sublayer.0.norm.b_2"]), bf16)
-            q, k_, v = (_rb(n1 @ _rb(sd[pre + f"self_attn.linears.{j}.weight"], bf16).t() + sd[pre + f"self_attn.linears.{j}.bias"], bf16)
+            q, k_, v = (_rb(_rg(n1 @ _rb(sd[pre + f"self_attn.linears.{j}.weight"], bf16).t() + sd[pre + f"self_attn.linears.{j}.bias"], rbw), bf16)
                         .view(B, S, h, dk).transpose(1, 2) for j in range(3))            # :199-201
-            sc = q @ k_.transpose(-2, -1) / math.sqrt(dk)              # :156
-            sc = sc.masked_fill(pad, float("-inf"))                    # :158-159
-            pa = torch.softmax(sc, dim=-1)                             # :161
-            pa = _rb(_drop(pa, keep.get(("attn", l)), p), bf16)        # :162-163
-            ctx = _rb((pa @ v).transpose(1, 2).contiguous().view(B, S, d), bf16)          # :207-209
-            att = ctx @ _rb(sd[pre + "self_attn.linears.3.weight"], bf16).t() + sd[pre + "self_attn.linears.3.bias"]
+            if rbw:
+                ka = keep.get(("attn", l))
+                ctx = _AttnCoreRounded.apply(q, k_, v, pad, ka, p if ka is not None else 0.0)
+                ctx = _rg(ctx.transpose(1, 2).contiguous().view(B, S, d), True)
+            else:
+                sc = q @ k_.transpose(-2, -1) / math.sqrt(dk)              # :156
+                sc = sc.masked_fill(pad, float("-inf"))                    # :158-159
+                pa = torch.softmax(sc, dim=-1)                             # :161
+                pa = _rb(_drop(pa, keep.get(("attn", l)), p), bf16)        # :162-163
+                ctx = _rb((pa @ v).transpose(1, 2).contiguous().view(B, S, d), bf16)      # :207-209
+            att = _rg(ctx @ _rb(sd[pre + "self_attn.linears.3.weight"], bf16).t() + sd[pre + "self_attn.linears.3.bias"], rbw)
             ko = keep.get(("attn_out", l))
             y = y + _drop(att, None if ko is None else ko.view(B, S, d), p)                # :113-114
             n2 = _rb(layer_norm_annotated(y, sd[pre + "sublayer.1.norm.a_2"], sd[pre + "sublayer.1.norm.b_2"]), bf16)
-            hid = torch.relu(n2 @ _rb(sd[pre + "feed_forward.w_1.weight"], bf16).t() + sd[pre + "feed_forward.w_1.bias"])
+            hid = torch.relu(_rg(n2 @ _rb(sd[pre + "feed_forward.w_1.weight"], bf16).t() + sd[pre + "feed_forward.w_1.bias"], rbw))
             kh = keep.get(("ffn_hidden", l))
             hid = _rb(_drop(hid, None if kh is None else kh.view(B, S, -1), p), bf16)      # :237
-            ff = hid @ _rb(sd[pre + "feed_forward.w_2.weight"], bf16).t() + sd[pre + "feed_forward.w_2.bias"]
+            ff = _rg(hid @ _rb(sd[pre + "feed_forward.w_2.weight"], bf16).t() + sd[pre + "feed_forward.w_2.bias"], rbw)
             kf = keep.get(("ffn_out", l))
             y = y + _drop(ff, None if kf is None else kf.view(B, S, d), p)
         y = layer_norm_annotated(y, sd["encoder.norm.a_2"], sd["encoder.norm.b_2"])        # :59
@@ -94,10 +161,10 @@ def encoder_scores(sd, x, mask, cfg, keep=None, bf16=False):
     return out.squeeze(dim=2)
 
 
-def scores_and_grads(sd, x, mask, cfg, loss_fn, keep=None, bf16=False, dtype=torch.float64):
+def scores_and_grads(sd, x, mask, cfg, loss_fn, keep=None, bf16=False, dtype=torch.float64, round_bwd=False):
     """(scores, loss, {key: grad}) in `dtype`; loss_fn maps scores [B, S] -> 0-dim."""
     p = {k: v.detach().to(dtype).clone().requires_grad_(True) for k, v in sd.items()}
-    s = encoder_scores(p, x.detach().to(dtype), mask, cfg, keep, bf16)
+    s = encoder_scores(p, x.detach().to(dtype), mask, cfg, keep, bf16, round_bwd)
     loss = loss_fn(s)
     grads = torch.autograd.grad(loss, list(p.values()), allow_unused=True)
     return s.detach(), loss.detach(), {k: (torch.zeros_like(p[k]) if g is None else g) for k, g in zip(p.keys(), grads)}

@@ -91,3 +91,42 @@ def test_ragged_queries_and_errors(tmp_path):
     open(empty, "w").write("# nothing\n")
     with pytest.raises(LtrError):
         data.load_svmlight(empty)
+
+
+def test_parser_never_reads_past_a_line(tmp_path):
+    """Every numeric parse is bounded by the line end (the mapping is not NUL-terminated and strtod skips '\\n'):
+    an empty value ("2:" at the end of a line) is malformed -- it must NOT swallow the next line's label --, so are
+    non-finite and over-long values; a file whose size is an exact multiple of the page size and that lacks a final
+    newline parses without touching the byte behind the mapping."""
+    import mmap
+    from ltr_mi355x import LtrError, data
+    for k, text in enumerate(["1 qid:1 1:0.5 2:\n7 qid:1 1:0.25\n", "1 qid:1 1:0.5 2:", "1 qid:1 1:nan\n", "1 qid:1 1:1e400\n",
+                              "1 qid:1 1:inf\n", "1 qid: 1:0.5\n", "1 qid:1 :0.5\n", "1 qid:1 1:" + "9" * 80 + "\n", "\n \n1e\n",
+                              "1 qid:1 1:0.5 2 :3\n", "1 qid:1 1:0.5x\n"]):
+        bad = str(tmp_path / f"bad{k}.txt")
+        with open(bad, "w") as f:
+            f.write(text)
+        with pytest.raises(LtrError, match="malformed"):
+            data.load_svmlight(bad)
+    page = mmap.PAGESIZE
+    line = "2 qid:7 1:0.5 2:-1.25 3:3\n"
+    last = "1 qid:8 1:0.125 3:"
+    n_lines = (2 * page - len(last) - 1) // len(line)
+    body = line * n_lines
+    fill = 2 * page - len(body) - len(last)
+    assert 1 <= fill < 60
+    text = body + last + "7" * fill            # last token ends exactly at the end of the mapping, no newline
+    assert len(text) == 2 * page
+    p = str(tmp_path / "page.txt")
+    with open(p, "w") as f:
+        f.write(text)
+    X, y, qid = data.load_svmlight(p, n_features=3, n_threads=3)
+    assert X.shape == (n_lines + 1, 3)
+    assert np.array_equal(X[0], np.float32([0.5, -1.25, 3.0])) and y[0] == 2 and qid[0] == 7
+    assert np.array_equal(X[-1], np.float32([0.125, 0.0, float("7" * fill)])) and y[-1] == 1 and qid[-1] == 8
+    # accepted spellings stay accepted: exponents, signs, leading '+', CRLF line ends, trailing comment
+    ok = str(tmp_path / "ok.txt")
+    with open(ok, "w") as f:
+        f.write("+1.5e0 qid:3 1:-2.5E-1 2:+4 # c\r\n0 qid:3 2:.5\r\n")
+    X, y, qid = data.load_svmlight(ok, n_features=2)
+    assert np.array_equal(X, np.float32([[-0.25, 4.0], [0.0, 0.5]])) and list(y) == [1.5, 0.0] and list(qid) == [3, 3]

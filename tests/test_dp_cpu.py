@@ -23,26 +23,50 @@ def _init_params():
 
 class OracleLocalStep:
     """Same contract as ltr_mi355x.scorer.FusedRanker: .flat = [grads | loss], p.grad aliases it,
-    .step(X, y, world_batch) leaves this rank's contribution scaled for the global batch."""
+    .step(X, y, world_batch) leaves this rank's contribution scaled for the global batch; with deferred=True also the
+    deferred-normalisation protocol (.flat_ext = [grads | loss | normaliser], step(defer_norm=True), finish_norm())."""
 
-    def __init__(self, params):
+    def __init__(self, params, loss="approxNDCG", deferred=True):
         import ltr_oracle as O
         self.O = O
         self.params = params
+        self.loss = loss
         n = sum(p.numel() for p in params)
-        self.flat = torch.zeros(n + 1, dtype=torch.float64)
+        ext = torch.zeros(n + 2, dtype=torch.float64)
+        self.flat = ext[:n + 1]
+        if deferred:
+            self.flat_ext = ext
+            self.finish_norm = self._finish_norm
+        self._norm = ext[n + 1:]
         self.seed_salt = -1        # QueryShardedTrainer must set the per-rank dropout salt
+        self.calls = []
         off = 0
         for p in params:
             p.grad = self.flat[off:off + p.numel()].view_as(p)
             off += p.numel()
 
-    def step(self, X, y, world_batch=None):
+    @property
+    def mean_kind(self):
+        return "batch" if self.loss == "approxNDCG" else "pairs"
+
+    def _finish_norm(self):
+        self.flat.div_(self._norm)
+
+    def step(self, X, y, world_batch=None, defer_norm=False):
+        self.calls.append("defer" if defer_norm else "prescaled")
         B = X.shape[0]
         gb = world_batch or B
         sd = dict(zip(KEYS, self.params))
         s = self.O.triple_layer_forward(X, sd).squeeze(-1)
-        loss = self.O.approx_ndcg(s, y) * (B / gb)          # mean over the GLOBAL batch
+        if self.loss == "approxNDCG":
+            loss = self.O.approx_ndcg(s, y) * (B if defer_norm else B / gb)      # sum over slates | mean over the GLOBAL batch
+            self._norm.fill_(float(B))
+        else:                                                                     # lambdaLoss reduction="mean" (lambdaL.py:88-89)
+            assert defer_norm or gb == B
+            losses, keep = self.O.lambda_pairs(s, y, weighing_scheme="ndcgLoss2PP_scheme")
+            pairs = losses[keep]
+            loss = -pairs.sum() if defer_norm else -pairs.mean()
+            self._norm.fill_(float(pairs.numel()))
         grads = torch.autograd.grad(loss, self.params)
         off = 0
         for g in grads:
@@ -59,7 +83,7 @@ def _data():
     return X, y
 
 
-def _worker(rank, world, port, out_dir):
+def _worker(rank, world, port, out_dir, loss_name, deferred):
     sys.path[:0] = [os.path.join(ROOT, "nn-with-pytorch-personalized-losses_amd"), os.path.join(ROOT, "oracle")]
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -72,7 +96,7 @@ def _worker(rank, world, port, out_dir):
                 p.copy_(q)
     sync_parameters(module)                             # ... and are synchronised from rank 0
     params = list(module)
-    local = OracleLocalStep(params)
+    local = OracleLocalStep(params, loss=loss_name, deferred=deferred)
     opt = torch.optim.Adam(params, lr=1e-2)
     tr = QueryShardedTrainer(local, opt)
     X, y = _data()
@@ -81,9 +105,14 @@ def _worker(rank, world, port, out_dir):
     for _ in range(3):
         losses.append(float(tr.step(X[lo:hi], y[lo:hi], global_batch=X.shape[0])))
     assert local.seed_salt == rank
-    # ragged shards (11 queries over 2 ranks: 6 + 5) with the DEFAULT global batch = all-reduced local sizes
+    # ragged shards (11 queries over 2 ranks: 6 + 5), no global batch given: the normaliser rides in the flat buffer
+    # (deferred protocol: ONE collective, no host read) -- or, for local steps without it, an all-reduce of the sizes
     lo, hi = shard_range(11, rank, world)
     losses.append(float(tr.step(X[lo:hi], y[lo:hi])))
+    if deferred:
+        assert local.calls == (["prescaled"] * 3 if loss_name == "approxNDCG" else ["defer"] * 3) + ["defer"]
+    else:
+        assert local.calls == ["prescaled"] * 4
     torch.save({"losses": losses, "flat": local.flat.clone(), "params": [p.detach().clone() for p in params]},
                os.path.join(out_dir, f"rank{rank}.pt"))
     dist.destroy_process_group()
@@ -96,15 +125,18 @@ def _free_port():
 
 
 @pytest.mark.timeout(300)
-def test_two_rank_allreduce_equals_single_process():
+@pytest.mark.parametrize("loss_name,deferred", [("approxNDCG", True), ("approxNDCG", False), ("lambdaLoss_mean", True)])
+def test_two_rank_allreduce_equals_single_process(loss_name, deferred):
+    """approxNDCG (batch mean) with and without the deferred-normalisation protocol, and lambdaLoss reduction="mean"
+    (lambdaL.py:88-89: mean over the GLOBAL kept pairs -- the count is all-reduced inside the same flat buffer)."""
     import ltr_oracle  # noqa: F401  (on sys.path via conftest)
     with tempfile.TemporaryDirectory() as d:
-        mp.spawn(_worker, args=(2, _free_port(), d), nprocs=2, join=True)
+        mp.spawn(_worker, args=(2, _free_port(), d, loss_name, deferred), nprocs=2, join=True)
         r0 = torch.load(os.path.join(d, "rank0.pt"), weights_only=True)
         r1 = torch.load(os.path.join(d, "rank1.pt"), weights_only=True)
     # single process, full batch
     params = _init_params()
-    local = OracleLocalStep(params)
+    local = OracleLocalStep(params, loss=loss_name)
     opt = torch.optim.Adam(params, lr=1e-2)
     X, y = _data()
     ref_losses = []

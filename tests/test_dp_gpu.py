@@ -164,6 +164,89 @@ def test_bench_self_launches_two_ranks():
     assert out["config"]["batch_per_gpu"] == 1024
 
 
+# ------------------------------------------------------------------------------------------------- RCCL + lambdaLoss mean
+def _lambda_worker(rank, world, port, out_dir, backend):
+    """lambdaLoss(reduction="mean") under data parallel (lambdaL.py:88-89: mean over the GLOBAL kept pairs): the kept-pair
+    count rides in the flat buffer.  backend "gloo": two ranks share the card; backend "nccl": ONE rank, world_size 1, in
+    a fresh process -- the RCCL branch (device-tensor all-reduce, destroy_process_group) executes on this one-GPU box."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    dev = torch.device("cuda:0")
+    if backend == "nccl":
+        torch.cuda.set_device(dev)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    net = _net(dev)
+    from ltr_mi355x.dp import QueryShardedTrainer, shard_range, sync_parameters
+    from ltr_mi355x.scorer import FusedRanker
+    sync_parameters(net)
+    out = {}
+    for name, kw in (("lambda_mean", dict(loss="lambdaLoss", weighing_scheme="ndcgLoss2PP_scheme", reduction="mean")),
+                     ("approx", dict(loss="approxNDCG"))):
+        with torch.no_grad():
+            for p, q in zip(net.parameters(), _net(dev).parameters()):
+                p.copy_(q)
+        ranker = FusedRanker(net, **kw)
+        tr = QueryShardedTrainer(ranker, torch.optim.SGD(net.parameters(), lr=0.5), always_collective=True)
+        assert tr.collective and tr.deferred
+        X, y = _data()
+        lo, hi = shard_range(23, rank, world)                 # 23 slates: ragged shards (12 + 11) on two ranks
+        losses = [float(tr.step(X[lo:hi].to(dev), y[lo:hi].to(dev))) for _ in range(2)]
+        out[name] = {"losses": losses, "flat": ranker.flat.cpu().clone(), "params": [p.detach().cpu().clone() for p in net.parameters()]}
+    out["backend"] = dist.get_backend()
+    torch.save(out, os.path.join(out_dir, f"rank{rank}.pt"))
+    dist.destroy_process_group()
+
+
+def _single_process_reference(dev):
+    from ltr_mi355x.scorer import FusedRanker
+    ref = {}
+    for name, kw in (("lambda_mean", dict(loss="lambdaLoss", weighing_scheme="ndcgLoss2PP_scheme", reduction="mean")),
+                     ("approx", dict(loss="approxNDCG"))):
+        net = _net(dev)
+        ranker = FusedRanker(net, **kw)
+        opt = torch.optim.SGD(net.parameters(), lr=0.5)
+        X, y = _data()
+        losses = []
+        for _ in range(2):
+            losses.append(float(ranker.step(X[:23].to(dev), y[:23].to(dev))))
+            opt.step()
+        ref[name] = {"losses": losses, "flat": ranker.flat.cpu().clone(), "params": [p.detach().cpu() for p in net.parameters()]}
+    return ref
+
+
+def _check_against_reference(r, ref):
+    for name in ("lambda_mean", "approx"):
+        assert max(abs(a - b) / abs(b) for a, b in zip(r[name]["losses"], ref[name]["losses"])) < 1e-5, name
+        top = float(ref[name]["flat"][:-1].abs().max())
+        assert float((r[name]["flat"][:-1] - ref[name]["flat"][:-1]).abs().max()) / top < 1e-5, name
+        for a, c in zip(r[name]["params"], ref[name]["params"]):
+            assert float((a - c).abs().max()) / max(float(c.abs().max()), 1e-30) < 1e-5, name
+
+
+@pytest.mark.timeout(600)
+def test_rccl_world_size_one_in_fresh_process():
+    """The `nccl` (= RCCL) branch executes on this box: init_process_group("nccl", world_size=1, device_id=...), the
+    all-reduce of the device-resident flat_ext buffer, destroy_process_group -- in a child started by mp.spawn from a
+    parent that has made no GPU call.  Results must equal the plain single-process steps."""
+    with tempfile.TemporaryDirectory() as d:
+        mp.spawn(_lambda_worker, args=(1, _free_port(), d, "nccl"), nprocs=1, join=True)
+        r = torch.load(os.path.join(d, "rank0.pt"), weights_only=True)
+    assert r["backend"] == "nccl"
+    _check_against_reference(r, _single_process_reference(torch.device("cuda:0")))
+
+
+@pytest.mark.timeout(600)
+def test_lambda_mean_two_ranks_equal_single_process():
+    with tempfile.TemporaryDirectory() as d:
+        mp.spawn(_lambda_worker, args=(2, _free_port(), d, "gloo"), nprocs=2, join=True)
+        r0 = torch.load(os.path.join(d, "rank0.pt"), weights_only=True)
+        r1 = torch.load(os.path.join(d, "rank1.pt"), weights_only=True)
+    for name in ("lambda_mean", "approx"):
+        assert r0[name]["losses"] == r1[name]["losses"] and torch.equal(r0[name]["flat"], r1[name]["flat"])
+    _check_against_reference(r0, _single_process_reference(torch.device("cuda:0")))
+
+
 # ------------------------------------------------------------------------------------------------- make_model networks
 def _enc_net(dev):
     sys.path.insert(0, os.path.join(ROOT, "nn-with-pytorch-personalized-losses_amd"))
