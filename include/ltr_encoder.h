@@ -100,6 +100,12 @@ int ltr_enc_attention_fwd(const uint16_t *qkv, const uint8_t *mask, int B, int S
 int ltr_enc_attention_bwd(const uint16_t *qkv, const uint16_t *ctx, const uint16_t *dctx, const uint8_t *mask, int B, int S, int h,
                           int dk, float drop_p, uint64_t seed, int stream_id, uint16_t *dqkv, void *stream);
 
+/* p_attn, the second value `attention()` returns (transformer.py:161-164; MultiHeadedAttention keeps it in `.attn`, :207):
+ * probs [B][h][S][S] fp32 = dropout(softmax(q k^T / sqrt(dk) masked)), from the same bf16 q, k and the same dropout stream
+ * as ltr_enc_attention_fwd.  Forward-only helper for callers that inspect the attention map; not on the training path. */
+int ltr_enc_attention_probs(const uint16_t *qkv, const uint8_t *mask, int B, int S, int h, int dk, float drop_p, uint64_t seed,
+                            int stream_id, float *probs, void *stream);
+
 /* ---- PositionwiseFeedForward + its residual tail (transformer.py:215-237, :113-114) without a [T][d_ff] tensor in HBM:
  * the hidden activation is produced 128 units at a time in registers and recomputed in the backward.
  *   forward    x2 = x1 + dropout(dropout(relu(n2 W1^T + b1)) W2^T + b2)      (streams: stream_hidden idx = t*dff + h,

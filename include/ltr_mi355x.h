@@ -194,6 +194,19 @@ int ltr_mlp_backward(int net, const float *X, int64_t n_docs, const float *packe
                      void *stream);
 int ltr_mlp_reduce_grads(int net, const float *partials, int grid, float *flat_grad, void *stream);
 
+/* The same forward / backward pair with ONE forward (what autograd does in the reference, main_batch_execution.py:128-170):
+ * ltr_mlp_forward_save also writes the post-activation hidden layers h1 / h2 (dropout applied) of every document to `acts`
+ * (ltr_mlp_acts_floats(net, n_docs) floats, 16-byte aligned: one lane-ordered 1 KiB fragment per 16-document tile and 16
+ * features), ltr_mlp_backward_saved reads them back instead of recomputing fc1 / fc2 (the backward kernel is bound by the
+ * fp32 matrix pipe, the round trip costs HBM bandwidth it does not use).  Used for slate lengths the one-launch fused
+ * step does not cover (BASELINE config 3: slate 512).  `dropout` only selects the ReLU-dropout slope (2) of the backward.
+ * Exact-fp32 library only (the split-precision variant returns LTR_ERR_PARAM). */
+int64_t ltr_mlp_acts_floats(int net, int64_t n_docs);      /* < 0: LTR_ERR_* */
+int ltr_mlp_forward_save(int net, const float *X, int64_t n_docs, const float *packed, int dropout, uint64_t seed,
+                         const uint8_t *keep1, const uint8_t *keep2, float *scores, float *acts, int grid, void *stream);
+int ltr_mlp_backward_saved(int net, const float *X, int64_t n_docs, const float *packed, int dropout, const float *acts,
+                           const float *dscores, float *partials, int grid, void *stream);
+
 /* One fused training pass over B slates of S documents (S in {32, 64, 128}): scorer forward, per-slate loss
  * (LTR_LOSS_*; labels [B][S]), loss backward, scorer backward -- scores never leave the CU, X is read once.
  *   slate_loss[b]  : per-slate loss (caller reduces: mean for approxNDCG, sum for ListNet)

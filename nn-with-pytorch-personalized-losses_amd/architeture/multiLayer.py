@@ -27,7 +27,15 @@ class FCModel(nn.Module):
         self.layers = nn.ModuleList(layers)
 
     def forward(self, x):
-        raise NotImplementedError("FCModel.forward on its own is not built on the MI355X path; it runs inside LTRModel")
+        """multiLayer.py:36-46 on its own: input norm, then Linear + dropout per layer, as ONE autograd node (gradients to
+        the parameters and to x)."""
+        from ltr_mi355x import blocks as B
+        spec = _enc.EncoderSpec(n_features=x.shape[-1], fc_sizes=[l.out_features for l in self.layers],
+                                input_norm=isinstance(self.input_norm, nn.LayerNorm), fc_dropout=self.dropout.p, n_layers=0, heads=1,
+                                d_ff=8, enc_dropout=0.0, has_encoder=False)
+        x3 = x if x.dim() == 3 else x.reshape(1, -1, x.shape[-1])
+        out = B.Features.apply(spec, False, x3, None, B.fresh_seed() if self.training else 0, self.training, *self._ltr_params())
+        return out.reshape(*x.shape[:-1], out.shape[-1]).to(x.dtype)
 
     def _ltr_params(self):
         out = [self.input_norm.weight, self.input_norm.bias] if isinstance(self.input_norm, nn.LayerNorm) else []
@@ -46,9 +54,15 @@ class OutputLayer(nn.Module):
         self.w_1 = nn.Linear(d_model, d_output)
 
     def forward(self, x):
-        raise NotImplementedError("OutputLayer.forward on its own is not built on the MI355X path; it runs inside LTRModel")
+        """multiLayer.py:107-113: w_1(x).squeeze(dim=2) -> [batch, slate] for d_output = 1, [batch, slate, d_output] otherwise."""
+        from ltr_mi355x import blocks as B
+        fn = B.score_linear if self.d_output == 1 else B.linear
+        return self.activation(fn(x, self.w_1.weight, self.w_1.bias).to(x.dtype).squeeze(dim=2))
 
     def score(self, x):
+        """multiLayer.py:115-124: the individual outputs summed when d_output > 1."""
+        if self.d_output > 1:
+            return self.forward(x).sum(-1)
         return self.forward(x)
 
 
@@ -88,16 +102,24 @@ class LTRModel(nn.Module):
         return (self.ltr_seed + 0x9E3779B97F4A7C15 * self._ltr_calls) & (2 ** 64 - 1)
 
     def prepare_for_output(self, x, mask, indices):
-        """Encoder output [batch, slate, d_model] (multiLayer.py:64-72); forward only on this path."""
+        """Encoder output [batch, slate, d_model] (multiLayer.py:64-72), one autograd node (gradients to every parameter
+        below the output layer and to x)."""
         spec = self._ltr_spec(x.shape[-1])
         return _enc.encoder_features(spec, x, mask, self._ltr_next_seed(), self.training, self._ltr_params())
 
     def forward(self, x, mask, indices):
+        """multiLayer.py:74-81.  d_output = 1: the whole network as one fused node -> [batch, slate]; d_output > 1: the
+        encoder node followed by the output layer's own node -> [batch, slate, d_output]."""
+        if self.output_layer.d_output != 1:
+            return self.output_layer(self.prepare_for_output(x, mask, indices))
         spec = self._ltr_spec(x.shape[-1])
         fn = _enc.EncoderScoresNative if _enc.native_enabled(spec) else _enc.EncoderScores
         return fn.apply(spec, x, mask, self._ltr_next_seed(), self.training, *self._ltr_params())
 
     def score(self, x, mask, indices):
+        """multiLayer.py:83-91: scores [batch, slate] (outputs summed when d_output > 1)."""
+        if self.output_layer.d_output != 1:
+            return self.output_layer.score(self.prepare_for_output(x, mask, indices))
         return self.forward(x, mask, indices)
 
     def ltr_approx_ndcg_loss(self, x, mask, y_true, eps=1e-10, padded_value_indicator=-1, alpha=1.):

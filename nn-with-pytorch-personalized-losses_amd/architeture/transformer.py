@@ -1,8 +1,9 @@
 """MI355X drop-in for architeture/transformer.py of the reference (the Annotated-Transformer encoder used as a
 slate encoder, :29-257).  Same class names, constructor signatures and state_dict keys; the arithmetic runs in
-the kernels of csrc/ltr_encoder.hip, driven as ONE fused forward/backward by `LTRModel` (architeture/multiLayer.py
--> ltr_mi355x/encoder.py).  The classes below are therefore parameter containers with the reference's layout:
-calling an inner block on its own (outside an LTRModel) is not part of the HIP path and raises."""
+the kernels of csrc/ltr_encoder.hip.  Inside an `LTRModel` (architeture/multiLayer.py -> ltr_mi355x/encoder.py) the
+whole network is ONE fused forward/backward; every block can also be called on its own like the reference's modules
+(ltr_mi355x/blocks.py: one autograd node per block over the same C-ABI entry points, gradients to parameters and inputs).
+Device tensors only.  `mask`: per-document padding ([batch, slate], optionally with singleton head / query axes)."""
 import copy
 
 import torch
@@ -14,10 +15,15 @@ def clones(module, N):
     return nn.ModuleList([copy.deepcopy(module) for _ in range(N)])
 
 
-def _inner(name):
-    raise NotImplementedError(
-        f"{name}.forward on its own is not built on the MI355X path: the encoder runs as one fused forward/backward "
-        "inside architeture.multiLayer.LTRModel (see ltr_mi355x/encoder.py)")
+def _blocks():
+    from ltr_mi355x import blocks
+    return blocks
+
+
+def _enc_spec(d, n_layers, h, d_ff, dropout):
+    from ltr_mi355x import encoder as _enc
+    return _enc.EncoderSpec(n_features=d, fc_sizes=[], input_norm=False, fc_dropout=0.0, n_layers=n_layers, heads=h, d_ff=d_ff,
+                            enc_dropout=dropout, has_encoder=True)
 
 
 class LayerNorm(nn.Module):
@@ -30,15 +36,8 @@ class LayerNorm(nn.Module):
         self.eps = eps
 
     def forward(self, x):
-        """Forward-only standalone use (fp32 in, fp32 out) through ltr_enc_layernorm_fwd."""
-        from ltr_mi355x import encoder as _enc
-        d = x.shape[-1]
-        T = x.numel() // d
-        with torch.cuda.device(x.device), torch.no_grad():
-            xf = x.detach().to(torch.float32).contiguous().view(T, d)
-            _, y = _enc.layernorm_fwd(xf, self.a_2.detach().float().contiguous(), self.b_2.detach().float().contiguous(), T, d,
-                                      self.eps, 0, want_f32=True)
-        return y.view(x.shape).to(x.dtype)
+        """transformer.py:78-88 through ltr_enc_layernorm_fwd / _bwd (fp32 in, fp32 out)."""
+        return _blocks().layer_norm(x, self.a_2, self.b_2, self.eps).to(x.dtype)
 
 
 class SublayerConnection(nn.Module):
@@ -50,7 +49,9 @@ class SublayerConnection(nn.Module):
         self.dropout = nn.Dropout(dropout)
 
     def forward(self, x, sublayer):
-        _inner("SublayerConnection")
+        """transformer.py:106-114.  `sublayer` is an arbitrary callable, so this block is the composition it is in the
+        reference: the HIP LayerNorm node, the callable, this module's own dropout, the residual add."""
+        return x + self.dropout(sublayer(self.norm(x)))
 
 
 class MultiHeadedAttention(nn.Module):
@@ -66,7 +67,15 @@ class MultiHeadedAttention(nn.Module):
         self.dropout = nn.Dropout(p=dropout)
 
     def forward(self, query, key, value, mask=None):
-        _inner("MultiHeadedAttention")
+        """transformer.py:187-212.  `self.attn` (the attention map the reference keeps, :207; nothing reads it) is not
+        materialised on this path: it stays None -- `attention()` returns the map when it is wanted."""
+        B = _blocks()
+        nb, S = query.shape[0], query.shape[1]
+        m8 = B.slate_mask(mask, nb, S, query.device)
+        p = self.dropout.p if self.training else 0.0
+        same = key is query and value is query
+        prm = [t for lin in self.linears for t in (lin.weight, lin.bias)]
+        return B.MultiHeadFn.apply(self.h, p, B.fresh_seed() if p > 0 else 0, same, query, key, value, m8, *prm).to(query.dtype)
 
 
 class PositionwiseFeedForward(nn.Module):
@@ -79,7 +88,11 @@ class PositionwiseFeedForward(nn.Module):
         self.dropout = nn.Dropout(dropout)
 
     def forward(self, x):
-        _inner("PositionwiseFeedForward")
+        """transformer.py:231-237."""
+        B = _blocks()
+        p = self.dropout.p if self.training else 0.0
+        return B.FeedForwardFn.apply(p, B.fresh_seed() if p > 0 else 0, x, self.w_1.weight, self.w_1.bias, self.w_2.weight,
+                                     self.w_2.bias).to(x.dtype)
 
 
 class EncoderLayer(nn.Module):
@@ -93,7 +106,15 @@ class EncoderLayer(nn.Module):
         self.size = size
 
     def forward(self, x, mask):
-        _inner("EncoderLayer")
+        """transformer.py:134-142 as ONE autograd node (both pre-norm residual sublayers; the fused-FFN kernels where the
+        shape allows)."""
+        B = _blocks()
+        at, ff = self.self_attn, self.feed_forward
+        spec = _enc_spec(self.size, 1, at.h, ff.w_1.out_features, self.sublayer[0].dropout.p)
+        m = B.slate_mask(mask, x.shape[0], x.shape[1], x.device)
+        if m is None:
+            m = torch.zeros(x.shape[:2], dtype=torch.uint8, device=x.device)
+        return B.Features.apply(spec, False, x, m, B.fresh_seed() if self.training else 0, self.training, *self._ltr_params()).to(x.dtype)
 
     def _ltr_params(self):
         at, ff = self.self_attn, self.feed_forward
@@ -114,7 +135,16 @@ class Encoder(nn.Module):
         self.position = position
 
     def forward(self, x, mask, indices):
-        _inner("Encoder")
+        """transformer.py:45-59 (position is None, :256) as ONE autograd node: N blocks + the final LayerNorm."""
+        B = _blocks()
+        if self.position:
+            raise NotImplementedError("positional encodings are not built on the HIP path (the reference never creates one)")
+        shape = self._ltr_shape()
+        spec = _enc_spec(self.layers[0].size, shape["n_layers"], shape["heads"], shape["d_ff"], shape["enc_dropout"])
+        if mask is None:
+            raise AttributeError("'NoneType' object has no attribute 'unsqueeze'")      # transformer.py:55
+        m = B.slate_mask(mask, x.shape[0], x.shape[1], x.device)
+        return B.Features.apply(spec, True, x, m, B.fresh_seed() if self.training else 0, self.training, *self._ltr_params()).to(x.dtype)
 
     def _ltr_params(self):
         out = []
@@ -129,8 +159,16 @@ class Encoder(nn.Module):
 
 
 def attention(query, key, value, mask=None, dropout=None):
-    """transformer.py:145-164; runs inside the fused encoder (ltr_enc_attention_fwd/bwd), not as a free function."""
-    _inner("attention")
+    """transformer.py:145-164: query / key / value [batch, heads, slate, d_k] -> (output [batch, heads, slate, d_k], p_attn
+    [batch, heads, slate, slate]).  `dropout`: None or an nn.Dropout module (applied to p_attn when it is in training mode).
+    The output carries the analytic backward (ltr_enc_attention_bwd); p_attn is returned detached."""
+    B = _blocks()
+    nb, h, S, dk = query.shape
+    m8 = B.slate_mask(mask, nb, S, query.device)
+    p = float(dropout.p) if (dropout is not None and getattr(dropout, "training", False)) else 0.0
+    seed = B.fresh_seed() if p > 0 else 0
+    out = B.AttentionCoreFn.apply(query, key, value, m8, p, seed)
+    return out.to(query.dtype), B.attention_probs(query, key, m8, p, seed).to(query.dtype)
 
 
 def make_transformer(N=6, d_ff=2048, h=8, dropout=0.1, n_features=136, positional_encoding=None):

@@ -1894,6 +1894,56 @@ inline size_t att_bwd_lds(int S) {
     return (size_t)(2 * Sp * kRowLd + 2 * kDkPad * tr_ld(Sp)) * sizeof(bf16_t) + (size_t)Sp * 12;
 }
 
+// p_attn of transformer.py:161-163 as a tensor (what `attention()` RETURNS next to its output; nothing on the training path
+// reads it): probs [B][h][S][S] fp32 = dropout(softmax(q k^T / sqrt(dk) + mask)), the same numbers attention_fwd_kernel
+// feeds into P.V before its bf16 rounding.  One wave per (slate-head, query); lanes over keys.  Not a hot kernel.
+__global__ void __launch_bounds__(256) attn_probs_kernel(AttArgs a, float *__restrict__ probs) {
+    const int lane = threadIdx.x & 63;
+    const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= (long long)a.B * a.h * a.S) return;
+    const int query = (int)(row % a.S), bh = (int)(row / a.S), b = bh / a.h, hd = bh % a.h;
+    const int d = a.h * a.dk, Sp = round_up(a.S, 32);
+    const bf16_t *base = a.qkv + (long long)b * a.S * 3 * d + hd * a.dk;
+    const bf16_t *qrow = base + (long long)query * 3 * d;
+    const float c2 = 1.44269504088896341f / sqrtf((float)a.dk);
+    float sc[8];                                             // S <= 512: 8 keys per lane
+    float m = -INFINITY;
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+        const int k = lane + 64 * t;
+        float v = -INFINITY;
+        if (k < a.S && !(a.mask && a.mask[(long long)b * a.S + k] == 1)) {
+            const bf16_t *krow = base + (long long)k * 3 * d + d;
+            float acc = 0.f;
+            for (int e = 0; e < a.dk; ++e) acc = fmaf(from_bf16(qrow[e]), from_bf16(krow[e]), acc);
+            v = acc * c2;
+        }
+        sc[t] = v;
+        m = fmaxf(m, v);
+    }
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    if (m == -INFINITY) m = 0.f;
+    float l = 0.f;
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+        sc[t] = __builtin_amdgcn_exp2f(sc[t] - m);
+        l += sc[t];
+    }
+    l = wave_sum(l);
+    const float inv = l > 0.f ? 1.f / l : 0.f;
+    const unsigned thr = drop_threshold(a.drop_p);
+    const float ks = thr ? 1.f / (1.f - a.drop_p) : 1.f;
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+        const int k = lane + 64 * t;
+        if (k < a.S) {
+            float pv = sc[t] * inv;
+            if (thr) pv = drop_keep(a.seed, a.stream_id, attn_idx(bh, Sp, query, k), thr) ? pv * ks : 0.f;
+            probs[row * a.S + k] = pv;
+        }
+    }
+}
+
 // one instantiation (and one set of per-device attribute flags) per kernel variant
 template <int KTMAX, bool FULL, bool BWD>
 int launch_att_tagged(const AttArgs &a, size_t lds, hipStream_t stream) {
@@ -2103,6 +2153,16 @@ int ltr_enc_attention_bwd(const uint16_t *qkv, const uint16_t *ctx, const uint16
     if (B == 0) return LTR_OK;
     AttArgs a{qkv, dctx, ctx, mask, dqkv, B, S, h, dk, drop_p, (unsigned long long)seed, stream_id};
     return dispatch_att<true>(a, att_bwd_lds(S), (hipStream_t)stream);
+}
+
+int ltr_enc_attention_probs(const uint16_t *qkv, const uint8_t *mask, int B, int S, int h, int dk, float drop_p, uint64_t seed,
+                            int stream_id, float *probs, void *stream) {
+    if (int rc = check_att(qkv, probs, B, S, h, dk, drop_p)) return rc;
+    if (B == 0) return LTR_OK;
+    AttArgs a{qkv, nullptr, nullptr, mask, nullptr, B, S, h, dk, drop_p, (unsigned long long)seed, stream_id};
+    const long long rows = (long long)B * h * S;
+    hipLaunchKernelGGL(attn_probs_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, a, probs);
+    return status();
 }
 
 int ltr_enc_ffn_supported(int d, int dff) { return (d == 64 || d == 128) && dff >= kFfnChunk && dff % kFfnChunk == 0; }

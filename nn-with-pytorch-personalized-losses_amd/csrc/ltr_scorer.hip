@@ -34,6 +34,15 @@
 #define LTR_SPLIT_BF16 0
 #endif
 
+// LTR_F16X2 = 1 builds the f16 x 2 split variant (libltr_mi355x_f16x2.so, same C ABI): fc1 / fc2 / dh1 -- the GEMMs whose
+// B operand lives in the wave's registers -- run on v_mfma_f32_16x16x32_f16 with every fp32 operand split into two f16
+// pieces (hi + lo, power-of-two pre-scaling per document / per weight matrix) and THREE of the four piece products
+// (hi hi, hi lo, lo hi; the dropped lo lo term is 2^-22 of the product) accumulated in fp32; the weight-gradient GEMMs stay on
+// the exact fp32 instruction.  4 B per element like fp32, 16/3 = 5.3 x the fp32 matrix rate.  See DESIGN.md section 4.3.
+#ifndef LTR_F16X2
+#define LTR_F16X2 0
+#endif
+
 using namespace ltr;
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -56,7 +65,7 @@ template <class N, int MODE>
 __host__ __device__ constexpr bool x_reg_prefetch() { return MODE == 0 /*MODE_FWD*/ || N::H1 <= 64; }
 
 enum { ACT_ID = 0, ACT_RELU_DROP = 1, ACT_SIGMOID = 2 };
-enum { MODE_FWD = 0, MODE_BWD = 1, MODE_FUSED = 2 };
+enum { MODE_FWD = 0, MODE_BWD = 1, MODE_FUSED = 2, MODE_BWD_SAVED = 3 };   // BWD_SAVED: h1 / h2 read back, not recomputed
 
 #if !LTR_SPLIT_BF16
 // TWO_: a two-Linear-layer scorer  w3 . act1(W1 x + b1) + b3  (no fc2: the commented-out 136-64-1 DoubleLayerNet variant of
@@ -82,7 +91,17 @@ struct NetT {
     static constexpr int W2F_OFF = W1F_OFF + NT1 * XT * 256;   // [NT2][H1T][64][4]
     static constexpr int W2T_OFF = W2F_OFF + NT2 * H1T * 256;  // [NT1][NT2][64][4]
     static constexpr int W3_OFF = W2T_OFF + NT1 * NT2 * 256;   // [NT2*16] then b3
+#if LTR_F16X2
+    // f16 hi / lo A-fragments in CONSUMPTION order [k-step P][output tile To][hi, lo][64 lanes][8 halfs]: 2 KiB per (P, To)
+    static constexpr int KP1 = (XT + 1) / 2, KP2 = (H1T + 1) / 2, KPT = (NT2 + 1) / 2;   // 32-wide k-steps = tile pairs
+    static constexpr int W1H_OFF = W3_OFF + NT2 * 16 + 16;
+    static constexpr int W2H_OFF = W1H_OFF + KP1 * NT1 * 512;
+    static constexpr int W2TH_OFF = W2H_OFF + (TWO_ ? 0 : KP2 * NT2 * 512);
+    static constexpr int PACKED = W2TH_OFF + (TWO_ ? 0 : KPT * NT1 * 512);
+    // 1 / scale of W1aug, W2aug, W2 ride in the spare floats of the w3 section: packed[W3_OFF + NT2*16 + 4 .. + 6]
+#else
     static constexpr int PACKED = W3_OFF + NT2 * 16 + 16;
+#endif
     // per-workgroup gradient partial (floats)
     static constexpr int P_W1 = 0;                             // [NT1*16][XT*16]
     static constexpr int P_W2 = P_W1 + NT1 * 16 * XT * 16;     // [NT2*16][H1T*16]
@@ -131,6 +150,8 @@ struct PipeArgs {
     const float *dscores_in; // MODE_BWD : [n_docs]
     float *slate_loss;       // MODE_FUSED: [B]
     float *partials;         // [grid][PART]
+    float *acts_out;         // MODE_FWD, optional: post-activation h1 / h2 of every 16-document wave tile, lane-ordered
+    const float *acts_in;    // MODE_BWD, optional: the same buffer -> fc1 / fc2 are NOT recomputed (ltr_mlp_backward_saved)
     const uint8_t *keep1;    // optional explicit dropout keep masks [n_docs][H1] / [n_docs][H2]
     const uint8_t *keep2;
     unsigned long long seed;
@@ -239,6 +260,72 @@ __device__ __forceinline__ void gemm_wx(__amdgpu_buffer_rsrc_t rsrc, int base_by
         __builtin_amdgcn_sched_barrier(0);
     }
 }
+
+#if LTR_F16X2
+typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
+#ifndef LTR_RING_H
+#define LTR_RING_H 8             // 16-byte fragment pieces in flight per wave (hi and lo of 4 (k-step, tile) pairs)
+#endif
+
+// The f16 x 2 form of gemm_wx: out^T tiles = W x B with B = the wave's activation tiles `bin` (accumulator layout).
+// k-step P covers input tiles 2P and 2P+1: element j of lane (q, d) is feature 16 (2P + (j >> 2)) + 4q + (j & 3) -- the
+// weight packing (pack_kernel) uses the same order.  Each document (lane & 15) is scaled by its own power of two so that its
+// largest |activation| lands in [2^13, 2^14); the weights were scaled the same way per matrix (inv_w = 1 / that scale); the
+// accumulators are un-scaled at the end.  Loop order: k-steps outermost (the hi / lo split of a k-step's 8 values per lane is
+// made once and used by every output tile; successive MFMAs of one accumulator are NT steps apart).
+template <int NT, int KT, int KMAX, int NMAX>
+__device__ __forceinline__ void gemm_wx_h(__amdgpu_buffer_rsrc_t rsrc, int base_bytes, int lane_off, const f32x4 (&bin)[KMAX],
+                                          f32x4 (&out)[NMAX], float inv_w) {
+    constexpr int KP = (KT + 1) / 2;
+    constexpr int NSTEP = KP * NT;
+    constexpr int NLOAD = 2 * NSTEP;
+    constexpr int R = LTR_RING_H;
+    static_assert(R % 2 == 0, "hi and lo pieces travel together");
+    f32x4 ring[R];
+#pragma unroll
+    for (int n = 0; n < R; ++n)
+        if (n < NLOAD) ring[n] = load_frag(rsrc, lane_off, base_bytes + n * 1024);
+    // per-document scale: max |b| over the document's K features (this lane's registers x the 4 q lanes of the document)
+    float m = 0.f;
+#pragma unroll
+    for (int T = 0; T < KT; ++T)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) m = fmaxf(m, fabsf(bin[T][r]));
+    m = fmaxf(m, __shfl_xor(m, 16, 64));
+    m = fmaxf(m, __shfl_xor(m, 32, 64));
+    int e = __builtin_amdgcn_frexp_expf(m);               // m = f 2^e, f in [0.5, 1); 0 for m == 0
+    e = e < -100 ? -100 : e;
+    const float sc = ldexpf(1.f, 14 - e);
+    const float un = ldexpf(inv_w, e - 14);
+#pragma unroll
+    for (int To = 0; To < NT; ++To) out[To] = f32x4{0.f, 0.f, 0.f, 0.f};
+    h16x8 bhi, blo;
+#pragma unroll
+    for (int n = 0; n < NSTEP; ++n) {
+        const int P = n / NT, To = n % NT;
+        if (To == 0) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int T = 2 * P + (j >> 2);
+                const float v = (T < KT ? bin[T < KT ? T : 0][j & 3] : 0.f) * sc;
+                const _Float16 h = (_Float16)v;
+                bhi[j] = h;
+                blo[j] = (_Float16)(v - (float)h);
+            }
+        }
+        const h16x8 ahi = __builtin_bit_cast(h16x8, ring[(2 * n) % R]);
+        const h16x8 alo = __builtin_bit_cast(h16x8, ring[(2 * n + 1) % R]);
+        if (2 * n + R < NLOAD) ring[(2 * n) % R] = load_frag(rsrc, lane_off, base_bytes + (2 * n + R) * 1024);
+        if (2 * n + 1 + R < NLOAD) ring[(2 * n + 1) % R] = load_frag(rsrc, lane_off, base_bytes + (2 * n + 1 + R) * 1024);
+        out[To] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ahi, bhi, out[To], 0, 0, 0);
+        out[To] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ahi, blo, out[To], 0, 0, 0);
+        out[To] = __builtin_amdgcn_mfma_f32_16x16x32_f16(alo, bhi, out[To], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int To = 0; To < NT; ++To) out[To] *= un;
+}
+#endif
 
 // Activation (+ dropout) on accumulator tiles; features >= H forced to 0 (only the partial last tile needs it).
 // ReLU + Dropout(0.5): 2*max(v,0) AND-ed with a 0 / ~0 mask made from the keep bit (4 VALU ops per value).
@@ -615,7 +702,7 @@ __global__ void __launch_bounds__(kThreads, 2) slate_pipeline_kernel(const PipeA
             if (LOSS != 1) stage_label(y, a.pad, yl[tid], gn[tid]);
             else yl[tid] = doc < (long long)a.B * a.S ? y : 0.f;
         }
-        if (MODE == MODE_BWD && tid < kTileDocs) {
+        if ((MODE == MODE_BWD || MODE == MODE_BWD_SAVED) && tid < kTileDocs) {
             const long long doc = doc_base + tid;
             dsc[tid] = doc < a.n_docs ? a.dscores_in[doc] : 0.f;
         }
@@ -627,36 +714,66 @@ __global__ void __launch_bounds__(kThreads, 2) slate_pipeline_kernel(const PipeA
         // during fc1/fc2 (xn was copied to LDS above)
         if (MODE == MODE_FWD && XPREF && st + (int)gridDim.x < a.n_super)
             load_x_tile<N>(xn, a, (long long)(st + gridDim.x) * kTileDocs + 16 * w, lane);
+        // ---- saved activations (ltr_mlp_forward_save -> ltr_mlp_backward_saved): one 1 KiB lane-ordered fragment per
+        //      (16-document wave tile, feature tile), h1 tiles then h2 tiles: coalesced 16 B per lane both ways
+        constexpr int ACT_FRAGS = N::NT1 + (N::TWO ? 0 : N::NT2);
+        constexpr bool saved = MODE == MODE_BWD_SAVED;
+        const size_t act_base = (((size_t)st * kWaves + w) * ACT_FRAGS) * 256 + (size_t)lane * 4;
         // ---- fc1
         f32x4 h1[N::H1T];
-        {
+        f32x4 h2[N::NT2];
+        if (saved) {
+            if (N::H1T > N::NT1) h1[N::H1T - 1] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int T = 0; T < N::NT1; ++T) h1[T] = *reinterpret_cast<const f32x4 *>(a.acts_in + act_base + (size_t)T * 256);
+#pragma unroll
+            for (int T = 0; T < N::NT2; ++T)
+                h2[T] = N::TWO ? h1[T] : *reinterpret_cast<const f32x4 *>(a.acts_in + act_base + (size_t)(N::NT1 + T) * 256);
+        } else {
             f32x4 xb[N::XT];
 #pragma unroll
             for (int T = 0; T < N::XT; ++T)
                 xb[T] = *reinterpret_cast<const f32x4 *>(Xs + my_row * LD + 16 * T + 4 * q);
             if (N::H1T > N::NT1) h1[N::H1T - 1] = f32x4{0.f, 0.f, 0.f, 0.f};
+#if LTR_F16X2
+            if (!LTR_SKIP(a, 16)) gemm_wx_h<N::NT1, N::XT>(wrsrc, N::W1H_OFF * 4, lane_off, xb, h1, w3s[N::NT2 * 16 + 4]);
+#else
             if (!LTR_SKIP(a, 16)) gemm_wx<N::NT1, N::XT>(wrsrc, N::W1F_OFF * 4, lane_off, xb, h1);
+#endif
             else
 #pragma unroll
                 for (int To = 0; To < N::NT1; ++To) h1[To] = xb[To];
         }
-        activate<N::A1, N::H1, N::NT1>(h1, q, a, 0, a.keep1, gdoc);
+        if (!saved) activate<N::A1, N::H1, N::NT1>(h1, q, a, 0, a.keep1, gdoc);
+        if (MODE == MODE_FWD && a.acts_out) {
+#pragma unroll
+            for (int T = 0; T < N::NT1; ++T) *reinterpret_cast<f32x4 *>(a.acts_out + act_base + (size_t)T * 256) = h1[T];
+        }
         {   // ones feature at index H1 (carries b2 through fc2 and db2 through dW2)
             constexpr int Tn = N::H1 / 16, p = N::H1 % 16;
             h1[Tn][p % 4] = (q == p / 4) ? 1.f : h1[Tn][p % 4];
         }
         LTR_STAMP(2)
         // ---- fc2
-        f32x4 h2[N::NT2];
-        if (N::TWO) {       // no fc2: the last hidden layer IS h1
+        if (saved) {
+        } else if (N::TWO) {       // no fc2: the last hidden layer IS h1
 #pragma unroll
             for (int To = 0; To < N::NT2; ++To) h2[To] = h1[To];
         } else {
+#if LTR_F16X2
+            if (!LTR_SKIP(a, 8)) gemm_wx_h<N::NT2, N::H1T>(wrsrc, N::W2H_OFF * 4, lane_off, h1, h2, w3s[N::NT2 * 16 + 5]);
+#else
             if (!LTR_SKIP(a, 8)) gemm_wx<N::NT2, N::H1T>(wrsrc, N::W2F_OFF * 4, lane_off, h1, h2);
+#endif
             else
 #pragma unroll
                 for (int To = 0; To < N::NT2; ++To) h2[To] = h1[To];
             activate<N::A2, N::H2, N::NT2>(h2, q, a, 1, a.keep2, gdoc);
+            if (MODE == MODE_FWD && a.acts_out) {
+#pragma unroll
+                for (int T = 0; T < N::NT2; ++T)
+                    *reinterpret_cast<f32x4 *>(a.acts_out + act_base + (size_t)(N::NT1 + T) * 256) = h2[T];
+            }
         }
         LTR_STAMP(3)
         // ---- fc3: s = w3 . h2 + b3, reduced over the 4 q-lanes of each document
@@ -807,7 +924,12 @@ __global__ void __launch_bounds__(kThreads, 2) slate_pipeline_kernel(const PipeA
         if (N::TWO) {       // the backward through fc3 above already produced dz1 (A2 = A1, "h2" = h1)
 #pragma unroll
             for (int To = 0; To < N::NT1; ++To) dz1[To] = h2[To];
-        } else if (!LTR_SKIP(a, 4)) gemm_wx<N::NT1, N::NT2>(wrsrc, N::W2T_OFF * 4, lane_off, h2, dz1);
+        }
+#if LTR_F16X2
+        else if (!LTR_SKIP(a, 4)) gemm_wx_h<N::NT1, N::NT2>(wrsrc, N::W2TH_OFF * 4, lane_off, h2, dz1, w3s[N::NT2 * 16 + 6]);
+#else
+        else if (!LTR_SKIP(a, 4)) gemm_wx<N::NT1, N::NT2>(wrsrc, N::W2T_OFF * 4, lane_off, h2, dz1);
+#endif
         else
 #pragma unroll
             for (int To = 0; To < N::NT1; ++To) dz1[To] = h2[To < N::NT2 ? To : 0];
@@ -931,8 +1053,67 @@ __global__ void pack_kernel(const float *__restrict__ W1, const float *__restric
         const int in = 16 * Ti + (lane & 15), o = 16 * T + 4 * (lane >> 4) + s;
         packed[N::W2T_OFF + e] = (o < N::H2 && in < N::H1) ? W2[o * N::H1 + in] : 0.f;
     }
-    for (int e = gt; e < N::NT2 * 16 + 16; e += stride)
-        packed[N::W3_OFF + e] = e < N::H2 ? w3[e] : (e == N::NT2 * 16 ? b3[0] : 0.f);
+#if LTR_F16X2
+    // ---- f16 hi / lo fragments of the same three matrices, each scaled by ONE power of two so that its largest |entry| lands
+    //      in [2^13, 2^14) (every workgroup recomputes the three maxima: 56 k reads, nothing to synchronise)
+    __shared__ float red[3][256];
+    float mx[3] = {0.f, 0.f, 0.f};
+    for (int e = threadIdx.x; e < N::H1 * (N::F + 1); e += blockDim.x) mx[0] = fmaxf(mx[0], fabsf(w1aug(e / (N::F + 1), e % (N::F + 1))));
+    for (int e = threadIdx.x; e < (N::TWO ? 0 : N::H2 * (N::H1 + 1)); e += blockDim.x) {
+        const float v = fabsf(w2aug(e / (N::H1 + 1), e % (N::H1 + 1)));
+        mx[1] = fmaxf(mx[1], v);
+        if (e % (N::H1 + 1) < N::H1) mx[2] = fmaxf(mx[2], v);
+    }
+    for (int k = 0; k < 3; ++k) red[k][threadIdx.x] = mx[k];
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o)
+            for (int k = 0; k < 3; ++k) red[k][threadIdx.x] = fmaxf(red[k][threadIdx.x], red[k][threadIdx.x + o]);
+        __syncthreads();
+    }
+    float scl[3], inv[3];
+    for (int k = 0; k < 3; ++k) {
+        int ex = __builtin_amdgcn_frexp_expf(red[k][0]);
+        ex = ex < -100 ? -100 : ex;
+        scl[k] = ldexpf(1.f, 14 - ex);
+        inv[k] = ldexpf(1.f, ex - 14);
+    }
+    uint16_t *ph = reinterpret_cast<uint16_t *>(packed);
+    auto put = [&](size_t off_halfs, int hh, float v) {          // half index hh inside a section -> hi or lo piece of v
+        const _Float16 hi = (_Float16)v;
+        const _Float16 out = ((hh >> 9) & 1) ? (_Float16)(v - (float)hi) : hi;
+        ph[off_halfs + hh] = __builtin_bit_cast(uint16_t, out);
+    };
+    auto geom = [](int hh, int NT, int &To, int &i, int &f) {   // (row tile, row in tile, feature) of half hh
+        const int j = hh & 7, lane = (hh >> 3) & 63, step = hh >> 10, P = step / NT;
+        To = step % NT;
+        i = lane & 15;
+        f = 32 * P + 16 * (j >> 2) + 4 * (lane >> 4) + (j & 3);
+    };
+    for (int hh = gt; hh < N::KP1 * N::NT1 * 1024; hh += stride) {
+        int To, i, f;
+        geom(hh, N::NT1, To, i, f);
+        put((size_t)N::W1H_OFF * 2, hh, w1aug(16 * To + i, f) * scl[0]);
+    }
+    for (int hh = gt; hh < (N::TWO ? 0 : N::KP2 * N::NT2 * 1024); hh += stride) {
+        int To, i, f;
+        geom(hh, N::NT2, To, i, f);
+        put((size_t)N::W2H_OFF * 2, hh, w2aug(16 * To + i, f) * scl[1]);
+    }
+    for (int hh = gt; hh < (N::TWO ? 0 : N::KPT * N::NT1 * 1024); hh += stride) {
+        int Ti, i, o;
+        geom(hh, N::NT1, Ti, i, o);
+        const int in = 16 * Ti + i;
+        put((size_t)N::W2TH_OFF * 2, hh, (o < N::H2 && in < N::H1) ? W2[o * N::H1 + in] * scl[2] : 0.f);
+    }
+#endif
+    for (int e = gt; e < N::NT2 * 16 + 16; e += stride) {
+        float v = e < N::H2 ? w3[e] : (e == N::NT2 * 16 ? b3[0] : 0.f);
+#if LTR_F16X2
+        if (e >= N::NT2 * 16 + 4 && e < N::NT2 * 16 + 7) v = inv[e - N::NT2 * 16 - 4];
+#endif
+        packed[N::W3_OFF + e] = v;
+    }
 }
 
 #endif
@@ -1008,6 +1189,9 @@ int pipeline_dispatch(int mode, const PipeArgs &a, int grid, hipStream_t stream)
     switch (mode) {
         case MODE_FWD: return launch_pipeline<N, MODE_FWD, 0>(a, grid, stream);
         case MODE_BWD: return launch_pipeline<N, MODE_BWD, 0>(a, grid, stream);
+#if !LTR_SPLIT_BF16
+        case MODE_BWD_SAVED: return launch_pipeline<N, MODE_BWD_SAVED, 0>(a, grid, stream);
+#endif
         default:
             switch (a.loss_kind) {
                 case 0: return launch_pipeline<N, MODE_FUSED, 0>(a, grid, stream);
@@ -1112,6 +1296,50 @@ int ltr_mlp_backward(int net, const float *X, int64_t n_docs, const float *packe
     a.partials = partials;
     LTR_FOR_NET(net, return pipeline_dispatch<NET>(MODE_BWD, a, grid, (hipStream_t)stream))
     return LTR_ERR_PARAM;
+}
+
+int64_t ltr_mlp_acts_floats(int net, int64_t n_docs) {
+    if (n_docs < 0) return LTR_ERR_SHAPE;
+    const int64_t tiles = (n_docs + kTileDocs - 1) / kTileDocs * kWaves;        // 16-document wave tiles, whole super-tiles
+    LTR_FOR_NET(net, return tiles * (NET::NT1 + (NET::TWO ? 0 : NET::NT2)) * 256)
+    return LTR_ERR_PARAM;
+}
+
+int ltr_mlp_forward_save(int net, const float *X, int64_t n_docs, const float *packed, int dropout, uint64_t seed,
+                         const uint8_t *keep1, const uint8_t *keep2, float *scores, float *acts, int grid, void *stream) {
+#if LTR_SPLIT_BF16
+    return LTR_ERR_PARAM;
+#else
+    PipeArgs a;
+    if (int rc = fill_common(a, net, X, n_docs, packed, dropout, seed, keep1, keep2)) return rc;
+    if (!scores || !acts) return LTR_ERR_NULL;
+    if (!aligned16(acts)) return LTR_ERR_ALIGN;
+    if (grid < 1) return LTR_ERR_PARAM;
+    if (a.n_super == 0) return LTR_OK;
+    a.scores_out = scores;
+    a.acts_out = acts;
+    if (grid > a.n_super) grid = a.n_super;
+    LTR_FOR_NET(net, return pipeline_dispatch<NET>(MODE_FWD, a, grid, (hipStream_t)stream))
+    return LTR_ERR_PARAM;
+#endif
+}
+
+int ltr_mlp_backward_saved(int net, const float *X, int64_t n_docs, const float *packed, int dropout, const float *acts,
+                           const float *dscores, float *partials, int grid, void *stream) {
+#if LTR_SPLIT_BF16
+    return LTR_ERR_PARAM;
+#else
+    PipeArgs a;
+    if (int rc = fill_common(a, net, X, n_docs, packed, dropout, 0, nullptr, nullptr)) return rc;
+    if (!dscores || !partials || !acts) return LTR_ERR_NULL;
+    if (!aligned16(acts)) return LTR_ERR_ALIGN;
+    if (grid < 1) return LTR_ERR_PARAM;
+    a.dscores_in = dscores;
+    a.partials = partials;
+    a.acts_in = acts;
+    LTR_FOR_NET(net, return pipeline_dispatch<NET>(MODE_BWD_SAVED, a, grid, (hipStream_t)stream))
+    return LTR_ERR_PARAM;
+#endif
 }
 
 int ltr_mlp_reduce_grads(int net, const float *partials, int grid, float *flat_grad, void *stream) {

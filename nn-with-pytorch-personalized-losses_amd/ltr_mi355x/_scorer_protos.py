@@ -9,6 +9,9 @@ PROTOTYPES = {
     "ltr_mlp_forward": (c_int, [c_int, P, c_int64, P, c_int, c_uint64, P, P, P, c_int, P]),
     "ltr_mlp_backward": (c_int, [c_int, P, c_int64, P, c_int, c_uint64, P, P, P, P, c_int, P]),
     "ltr_mlp_reduce_grads": (c_int, [c_int, P, c_int, P, P]),
+    "ltr_mlp_acts_floats": (c_int64, [c_int, c_int64]),
+    "ltr_mlp_forward_save": (c_int, [c_int, P, c_int64, P, c_int, c_uint64, P, P, P, P, c_int, P]),
+    "ltr_mlp_backward_saved": (c_int, [c_int, P, c_int64, P, c_int, P, P, P, c_int, P]),
     "ltr_fused_step": (c_int, [c_int, c_int, P, P, c_int, c_int, P, c_int, c_uint64, P, P, c_float, c_float, c_float,
                                c_int, c_float, P, P, c_int, P]),
     "ltr_debug_set_stamps": (c_int, [P, c_int]),

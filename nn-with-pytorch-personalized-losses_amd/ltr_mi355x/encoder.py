@@ -32,7 +32,7 @@ class GemmDesc(ctypes.Structure):
                 ("drop_stream", ctypes.c_int32), ("reserved", ctypes.c_int32)]
 
 
-def gemm(A, B, M, N, K, *, a_kmajor=False, b_kmajor=False, lda=None, ldb=None, Cf=None, Cb=None, bias=None, residual=None,
+def gemm(A, B, M, N, K, *, a_kmajor=False, b_kmajor=False, lda=None, ldb=None, ldc=None, Cf=None, Cb=None, bias=None, residual=None,
          gate=None, gate_scale=1.0, relu=False, drop_p=0.0, seed=0, drop_stream=0, splits=1):
     """C[m][n] = sum_k A(m,k) B(n,k) (+ epilogue) -> ltr_enc_gemm_bf16.  A, B: int16 tensors of bf16 bits."""
     d = GemmDesc()
@@ -40,7 +40,7 @@ def gemm(A, B, M, N, K, *, a_kmajor=False, b_kmajor=False, lda=None, ldb=None, C
     d.M, d.N, d.K = M, N, K
     d.lda = lda if lda is not None else (M if a_kmajor else K)
     d.ldb = ldb if ldb is not None else (N if b_kmajor else K)
-    d.ldc = N
+    d.ldc = ldc if ldc is not None else N
     d.a_kmajor, d.b_kmajor, d.splits, d.relu = int(a_kmajor), int(b_kmajor), int(splits), int(relu)
     d.Cf, d.Cb, d.bias, d.residual, d.gate = _ptr(Cf), _ptr(Cb), _ptr(bias), _ptr(residual), _ptr(gate)
     d.gate_scale, d.drop_p, d.seed, d.drop_stream = float(gate_scale), float(drop_p), int(seed) & (2 ** 64 - 1), int(drop_stream)
@@ -126,11 +126,12 @@ def _dw_splits(M, N, K):
     return max(1, min(s, (K + 255) // 256))
 
 
-def _weight_grad(dy, x, T, n_out, n_in):
-    """dW [n_out][n_in] = dy^T x over the T tokens (split-K GEMM + fixed-order reduce)."""
+def _weight_grad(dy, x, T, n_out, n_in, lda=None):
+    """dW [n_out][n_in] = dy^T x over the T tokens (split-K GEMM + fixed-order reduce); `lda`: row stride of dy when it is a
+    column slice of a wider tensor."""
     splits = _dw_splits(n_out, n_in, T)
     parts = torch.empty((splits, n_out, n_in), dtype=torch.float32, device=dy.device)
-    gemm(dy, x, n_out, n_in, T, a_kmajor=True, b_kmajor=True, Cf=parts, splits=splits)
+    gemm(dy, x, n_out, n_in, T, a_kmajor=True, b_kmajor=True, lda=lda, Cf=parts, splits=splits)
     return sum_partials(parts, splits, n_out * n_in).view(n_out, n_in) if splits > 1 else parts.view(n_out, n_in)
 
 
@@ -376,14 +377,22 @@ class EncoderScores(torch.autograd.Function):
             check(lib().ltr_enc_score_bwd(_ptr(st["final_x"]), _ptr(fa), _ptr(fb), _ptr(prm[-2]), _ptr(ds), T, d, LN_EPS,
                                           1 if spec.has_encoder else 0, _ptr(dx), _ptr(parts), nblk, _stream()), "ltr_enc_score_bwd")
             with deferred_reductions():
-                grads = _body_backward(spec, seed, st, dx, sum_partials(parts, nblk, 3 * d + 8))
+                grads = _with_tail(spec, _body_backward(spec, seed, st, dx)[0], sum_partials(parts, nblk, 3 * d + 8))
         out = [g if g is None else g.to(dt).reshape(p.shape) for g, dt, p in zip(grads, ctx.param_dtypes, prm)]
         return (None, None, None, None, None, *out)
 
 
-def _body_backward(spec, seed, st, dx, tail):
-    """Everything below the scoring tail: `dx` = d loss / d (encoder output before the final norm) [T, d], `tail` = the
-    reduced tail partials (d a_2 | d b_2 | d w | d bias).  Returns the gradient list in parameter order."""
+def _with_tail(spec, body, tail):
+    """Body gradients + the reduced tail partials (d a_2 | d b_2 | d w | d bias) -> the full list in parameter order."""
+    d = spec.d_model
+    norm = [tail[:d], tail[d:2 * d]] if spec.has_encoder else []
+    return body + norm + [tail[2 * d:3 * d].view(1, d), tail[3 * d:3 * d + 1]]
+
+
+def _body_backward(spec, seed, st, dx, want_dx=False):
+    """Everything below the final norm / scoring tail: `dx` = d loss / d (last residual-stream value) [T, d] (accumulated
+    into in place).  Returns (gradient list of the FC + encoder-block parameters in parameter order, d loss / d input
+    features [T, F] fp32 if want_dx else None)."""
     B, S, F = st["dims"]
     T = B * S
     p_fc, p_enc = st["p"]
@@ -391,14 +400,10 @@ def _body_backward(spec, seed, st, dx, tail):
     fc_w16, enc_w16 = st["fc_w16"], st["enc_w16"]
     dev = dx.device
     d = spec.d_model
-    grads = [None] * len(prm)
     n_fc0 = 2 if spec.input_norm else 0
     n_fc = n_fc0 + 2 * len(spec.fc_sizes)
-    g = tail
-    grads[-2] = g[2 * d:3 * d].view(1, d)
-    grads[-1] = g[3 * d:3 * d + 1]
+    grads = [None] * (n_fc + 16 * spec.n_layers)
     if spec.has_encoder:
-        grads[-4], grads[-3] = g[:d], g[d:2 * d]
         h, dk, dff = spec.heads, spec.dk, spec.d_ff
         for l in reversed(range(spec.n_layers)):
             base = n_fc + 16 * l
@@ -440,13 +445,14 @@ def _body_backward(spec, seed, st, dx, tail):
         dy, gb = _drop_cast_colsum(dx, T, n_out, p_fc, seed, stream_fc(i))
         grads[n_fc0 + 2 * i] = _weight_grad(dy, st["fc_in"][i], T, n_out, n_in)
         grads[n_fc0 + 2 * i + 1] = gb
-        if i > 0 or spec.input_norm:
+        if i > 0 or spec.input_norm or want_dx:
             dx = torch.empty((T, n_in), dtype=torch.float32, device=dev)
             gemm(dy, fc_w16[i], T, n_in, n_out, b_kmajor=True, Cf=dx)
     if spec.input_norm:
         scratch = torch.zeros((T, F), dtype=torch.float32, device=dev)
         grads[0], grads[1] = layernorm_bwd(st["xin"], prm[0], dx, T, F, STD_LN_EPS, 1, scratch)
-    return grads
+        dx = scratch
+    return grads, (dx if want_dx else None)
 
 
 class EncSpec(ctypes.Structure):
@@ -581,21 +587,15 @@ class EncoderApproxNDCG(torch.autograd.Function):
             with deferred_reductions():
                 # the backward accumulates into its dx argument in place: hand it a copy, so that a second backward over
                 # the same graph (retain_graph=True / gradient accumulation over one forward) starts from the tail's dx again
-                grads = _body_backward(ctx.spec, ctx.seed, st, ctx.dx.clone(), ctx.tail)
+                grads = _with_tail(ctx.spec, _body_backward(ctx.spec, ctx.seed, st, ctx.dx.clone())[0], ctx.tail)
             scale = go.detach().to(torch.float32)
             out = [None if g is None else (g * scale).to(dt).reshape(p.shape) for g, dt, p in zip(grads, ctx.param_dtypes, st["prm"])]
         return (None, None, None, None, None, None, None, None, None, *out)
 
 
 def encoder_features(spec, x, mask, seed, training, params):
-    """prepare_for_output (multiLayer.py:64-72): the encoder output [B, S, d_model] in fp32.  Forward only (no autograd
-    node): gradients flow through EncoderScores, which covers the output layer too."""
-    require_device(x, *params)
-    with torch.cuda.device(x.device), torch.no_grad():
-        st = _run_forward(spec, x, mask, seed, training, params)
-        B, S, _ = st["dims"]
-        out = st["final_x"]
-        if spec.has_encoder:
-            prm = st["prm"]
-            _, out = layernorm_fwd(out, prm[-4], prm[-3], B * S, spec.d_model, LN_EPS, 0, want_f32=True)
-        return out.view(B, S, spec.d_model)
+    """prepare_for_output (multiLayer.py:64-72): the encoder output [B, S, d_model] in fp32, with its analytic backward
+    (parameters and input): ltr_mi355x.blocks.Features over the FC + encoder-block (+ final norm) parameters."""
+    from .blocks import Features
+    body = list(params[:-2])                       # everything but the output layer
+    return Features.apply(spec, spec.has_encoder, x, mask, seed, training, *body)

@@ -227,6 +227,7 @@ class FusedRanker:
         self.partials = torch.empty(self.grid * self.info.partial_floats, dtype=torch.float32, device=dev)
         self._loss_out = self.flat[self.info.n_params]
         self._slate = None
+        self._acts = None              # saved hidden activations of the three-launch path (grown on demand)
         self._calls = 0
         self.seed_salt = 0             # per-rank salt of the dropout stream (data parallel)
         self.kernel_events = None      # optional (start, end) torch.cuda.Event pair bracketing the pipeline kernel
@@ -349,14 +350,20 @@ class FusedRanker:
         return self._loss_out
 
     def _step_three_launches(self, h, x2, yy, B, S, dropout, seed, k1, k2, scale, lambda_mean, defer_norm=False):
-        """Any slate length (and lambdaLoss "mean"): scorer forward launch -> loss kernel (forward + dL/dscores)
-        -> scorer backward launch (recomputes the forward from X with the same dropout stream)."""
+        """Any slate length (and lambdaLoss "mean"): scorer forward launch (writes the scores AND the post-activation
+        hidden layers, 1 152 B per document for the 136-wide net) -> loss kernel (forward + dL/dscores) -> scorer backward
+        launch that reads h1 / h2 back instead of recomputing fc1 / fc2: ONE forward, like the reference's autograd
+        (main_batch_execution.py:128-170).  The backward kernel is bound by the fp32 matrix pipe; the activation round trip
+        rides on HBM bandwidth it leaves idle."""
         n = B * S
         dev = self.device
         scores = torch.empty(n, dtype=torch.float32, device=dev)
         ds = torch.empty(n, dtype=torch.float32, device=dev)
-        check(h.ltr_mlp_forward(self.net, _ptr(x2), n, _ptr(self.packed), int(dropout), seed, _ptr(k1), _ptr(k2),
-                                _ptr(scores), self.grid, _stream()), "ltr_mlp_forward")
+        n_acts = int(h.ltr_mlp_acts_floats(self.net, n))
+        if self._acts is None or self._acts.numel() < n_acts:
+            self._acts = torch.empty(n_acts, dtype=torch.float32, device=dev)
+        check(h.ltr_mlp_forward_save(self.net, _ptr(x2), n, _ptr(self.packed), int(dropout), seed, _ptr(k1), _ptr(k2),
+                                     _ptr(scores), _ptr(self._acts), self.grid, _stream()), "ltr_mlp_forward_save")
         if self.loss_kind == LOSS_APPROXNDCG:
             check(h.ltr_approxndcg_fwd_bwd(_ptr(scores), _ptr(yy), B, S, self.alpha, self.eps, self.pad, scale,
                                            _ptr(self._slate), _ptr(ds), _stream()), "ltr_approxndcg_fwd_bwd")
@@ -370,8 +377,8 @@ class FusedRanker:
                                        _ptr(self._slate), _ptr(count), _ptr(ds), _stream()), "ltr_lambda_fwd_bwd")
         if self.kernel_events is not None:
             self.kernel_events[0].record()
-        check(h.ltr_mlp_backward(self.net, _ptr(x2), n, _ptr(self.packed), int(dropout), seed, _ptr(k1), _ptr(k2),
-                                 _ptr(ds), _ptr(self.partials), self.grid, _stream()), "ltr_mlp_backward")
+        check(h.ltr_mlp_backward_saved(self.net, _ptr(x2), n, _ptr(self.packed), int(dropout), _ptr(self._acts), _ptr(ds),
+                                       _ptr(self.partials), self.grid, _stream()), "ltr_mlp_backward_saved")
         if self.kernel_events is not None:
             self.kernel_events[1].record()
         check(h.ltr_mlp_reduce_grads(self.net, _ptr(self.partials), self.grid, _ptr(self.flat_grad), _stream()),

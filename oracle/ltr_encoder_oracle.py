@@ -106,7 +106,9 @@ def encoder_scores(sd, x, mask, cfg, keep=None, bf16=False, round_bwd=False):
     """Scores [B, S] of a `make_model` network.
       sd    {state_dict key: tensor} (reference key names)
       x     [B, S, F];  mask [B, S] (1 / True = padded) or None when there is no encoder
-      cfg   dict(n_fc, input_norm, fc_dropout, n_layers, heads, enc_dropout, has_encoder)
+      cfg   dict(n_fc, input_norm, fc_dropout, n_layers, heads, enc_dropout, has_encoder); optional keys for the blocks called
+            on their own (tests/test_blocks_gpu.py): final_norm (default True: Encoder.norm, transformer.py:59; False = a bare
+            EncoderLayer), output ("scores", default | "features": stop before the output layer = prepare_for_output)
       keep  None (eval) or {site: mask}: ("fc", i) -> [B*S, out_i]; ("attn", l) -> [B, h, S, S];
             ("attn_out", l), ("ffn_out", l) -> [B*S, d];  ("ffn_hidden", l) -> [B*S, d_ff]
       bf16       round where the HIP FORWARD rounds (operands of every GEMM, saved activations, P, ctx)
@@ -156,18 +158,31 @@ def encoder_scores(sd, x, mask, cfg, keep=None, bf16=False, round_bwd=False):
             ff = _rg(hid @ _rb(sd[pre + "feed_forward.w_2.weight"], bf16).t() + sd[pre + "feed_forward.w_2.bias"], rbw)
             kf = keep.get(("ffn_out", l))
             y = y + _drop(ff, None if kf is None else kf.view(B, S, d), p)
-        y = layer_norm_annotated(y, sd["encoder.norm.a_2"], sd["encoder.norm.b_2"])        # :59
-    out = y @ sd["output_layer.w_1.weight"].t() + sd["output_layer.w_1.bias"]             # multiLayer.py:113
+        if cfg.get("final_norm", True):
+            y = layer_norm_annotated(y, sd["encoder.norm.a_2"], sd["encoder.norm.b_2"])    # :59
+    if cfg.get("output", "scores") == "features":
+        return y
+    W, b = sd["output_layer.w_1.weight"], sd["output_layer.w_1.bias"]
+    if W.shape[0] > 1:          # d_output > 1 runs as a bf16-operand GEMM on the HIP path (d_output = 1: the fp32 scoring tail)
+        out = _rg(_rb(y, bf16) @ _rb(W, bf16).t() + b, rbw)
+    else:
+        out = y @ W.t() + b                                                                # multiLayer.py:113
     return out.squeeze(dim=2)
 
 
-def scores_and_grads(sd, x, mask, cfg, loss_fn, keep=None, bf16=False, dtype=torch.float64, round_bwd=False):
-    """(scores, loss, {key: grad}) in `dtype`; loss_fn maps scores [B, S] -> 0-dim."""
+def scores_and_grads(sd, x, mask, cfg, loss_fn, keep=None, bf16=False, dtype=torch.float64, round_bwd=False, want_dx=False):
+    """(scores, loss, {key: grad}) in `dtype`; loss_fn maps scores [B, S] -> 0-dim.  want_dx: the gradient w.r.t. the input
+    features is returned under the key "__x__"."""
     p = {k: v.detach().to(dtype).clone().requires_grad_(True) for k, v in sd.items()}
-    s = encoder_scores(p, x.detach().to(dtype), mask, cfg, keep, bf16, round_bwd)
+    xin = x.detach().to(dtype).clone().requires_grad_(bool(want_dx))
+    s = encoder_scores(p, xin, mask, cfg, keep, bf16, round_bwd)
     loss = loss_fn(s)
-    grads = torch.autograd.grad(loss, list(p.values()), allow_unused=True)
-    return s.detach(), loss.detach(), {k: (torch.zeros_like(p[k]) if g is None else g) for k, g in zip(p.keys(), grads)}
+    leaves = list(p.values()) + ([xin] if want_dx else [])
+    grads = torch.autograd.grad(loss, leaves, allow_unused=True)
+    out = {k: (torch.zeros_like(p[k]) if g is None else g) for k, g in zip(p.keys(), grads)}
+    if want_dx:
+        out["__x__"] = grads[-1] if grads[-1] is not None else torch.zeros_like(xin)
+    return s.detach(), loss.detach(), out
 
 
 def config_of(model_kwargs, n_features):

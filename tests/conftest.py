@@ -49,9 +49,10 @@ def golden(group):
 
 def _manifest():
     """manifest.json (round 1: approx / listnet / lambda / ordinal / scorers) + manifest_r2.json (risk / metrics) +
-    manifest_r3.json (encoder)."""
+    manifest_r3.json (encoder) + manifest_r4.json (encoder_c5: the benched config-5 network; blocks: every building block
+    of transformer.py / multiLayer.py called on its own)."""
     out = {}
-    for name in ("manifest.json", "manifest_r2.json", "manifest_r3.json"):
+    for name in ("manifest.json", "manifest_r2.json", "manifest_r3.json", "manifest_r4.json"):
         with open(os.path.join(GOLDEN, name)) as f:
             out.update({k: v for k, v in json.load(f).items() if not k.startswith("_")})
     return out
@@ -68,6 +69,24 @@ def relerr(a, b):
     if a.size == 0:
         return 0.0
     return float(np.abs(a - b).max()) / max(float(np.abs(b).max()), 1e-30)
+
+
+def seeded_state_dict(shapes, seed):
+    """The weight recipe of tests/golden/make_golden_r4.py (numpy PCG64): the config-5 fixture stores the seed, not 3.6 M
+    weights."""
+    rng = np.random.default_rng(seed)
+    out = {}
+    for key, shape in shapes:
+        shape = tuple(shape)
+        if len(shape) == 2:
+            a = float(np.sqrt(6.0 / (shape[0] + shape[1])))
+            v = rng.uniform(-a, a, size=shape)
+        else:
+            v = 0.1 * rng.standard_normal(size=shape)
+            if key.endswith("a_2") or key.endswith("norm.weight"):
+                v = 1.0 + v
+        out[key] = __import__('torch').from_numpy(v.astype(np.float32))
+    return out
 
 
 @pytest.fixture(scope="session")

@@ -125,3 +125,45 @@ def test_gemm_descriptor_layout_matches_the_header():
             names += [n.strip(" *") for n in m.group(1).split(",")]
     assert names == [f[0] for f in GemmDesc._fields_], names
     assert ctypes.sizeof(GemmDesc) == 144
+
+
+def test_round3_fixtures_are_complete():
+    """tests/golden/make_golden_r4.py: the benched config-5 network (weights by seed) and the stand-alone blocks -- every
+    array the GPU tests read exists with the declared shape; the block modules expose the reference's state_dict keys."""
+    from architeture import transformer as TR
+    g5 = golden("encoder_c5")
+    case = g5.cases[0]
+    assert (case["B"], case["S"], case["n_features"]) == (2, 256, 136) and case["transformer"]["N"] == 6
+    assert g5.arr(case, "scores").shape == (2, 256) and g5.arr(case, "mask").sum() == 29
+    for k, sh in case["shapes"]:
+        if len(sh) == 1:
+            assert g5.arr(case, "g/" + k).shape == tuple(sh)
+        else:
+            assert g5.arr(case, "grows/" + k).shape == (min(4, sh[0]), sh[1]) and g5.arr(case, "gstat/" + k).shape == (3,)
+    gb = golden("blocks")
+    ids = {c["id"] for c in gb.cases}
+    assert {"LayerNorm", "SublayerConnection_ffn", "MultiHeadedAttention_self", "MultiHeadedAttention_cross", "attention_fn",
+            "PositionwiseFeedForward", "EncoderLayer", "Encoder", "FCModel_norm", "FCModel_plain", "OutputLayer_d1_forward",
+            "OutputLayer_d3_forward", "OutputLayer_d3_score", "LTRModel_d3_forward", "LTRModel_d3_score",
+            "LTRModel_prepare_for_output"} <= ids
+    layer = next(c for c in gb.cases if c["id"] == "EncoderLayer")
+    mod = TR.EncoderLayer(32, TR.MultiHeadedAttention(4, 32, 0.1), TR.PositionwiseFeedForward(32, 64, 0.1), 0.1)
+    assert list(mod.state_dict().keys()) == layer["keys"]
+
+
+def test_oracle_reproduces_reference_on_the_benched_config5_network():
+    """fp32 oracle vs the stored reference numbers of the 3.6 M-parameter network (scores, loss, vector gradients, matrix rows)."""
+    from conftest import seeded_state_dict
+    g5 = golden("encoder_c5")
+    case = g5.cases[0]
+    sd = seeded_state_dict(case["shapes"], case["weight_seed"])
+    x, y, mask = (torch.from_numpy(g5.arr(case, n)) for n in ("x", "y", "mask"))
+    cfg = EO.config_of(dict(fc_model=case["fc_model"], transformer=case["transformer"]), case["n_features"])
+    s, loss, grads = EO.scores_and_grads(sd, x, mask, cfg, lambda v: O.approx_ndcg(v, y.to(v.dtype)), dtype=torch.float32)
+    want = g5.arr(case, "scores")
+    assert np.abs(s.numpy() - want).max() <= 5e-5 * np.abs(want).max()
+    gmax = max(float(np.abs(g5.arr(case, "g/" + k)).max()) for k, sh in case["shapes"] if len(sh) == 1)
+    for k, sh in case["shapes"]:
+        ref = g5.arr(case, "g/" + k) if len(sh) == 1 else g5.arr(case, "grows/" + k)
+        got = grads[k].numpy() if len(sh) == 1 else grads[k][:4].numpy()
+        assert np.abs(got - ref).max() / max(np.abs(ref).max(), 1e-3 * gmax) <= 5e-4, k

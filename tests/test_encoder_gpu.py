@@ -4,21 +4,27 @@ Tolerances (stated here, used below):
   * kernels in isolation, on bf16-representable inputs, vs torch fp64 on the SAME inputs:
         GEMM / column sums / LayerNorm / scoring tail: 2e-5 (fp32 accumulation order only; bf16 outputs: 2^-8 rounding)
         attention: 1e-2 of the tensor's max (P, dS and the outputs are rounded to bf16 inside the kernel)
-  * whole network vs the reference's golden vectors (fp32 CPU, tests/golden/encoder.npz): scores / loss 3e-2; parameter
-    gradients: cosine of the whole gradient > 0.99 and every tensor within 0.35 of its scale (bf16 rounding flips ReLU
-    units whose pre-activation is near zero -- O(1) for that unit in these tiny nets) -- the bf16-operand arithmetic
-    BASELINE config 5 asks for, NOT the 1e-5 bar of the fp32 rows;
-  * whole network vs the oracle with the same rounding points in its forward (bf16=True, fp64 otherwise): scores 1e-2,
-    every parameter gradient within 5e-2 in L2 and 0.15 in max-norm of max(its own scale, 5 % of the case's largest
-    gradient entry) -- the fp64 oracle and the fp32-accumulating kernels still disagree on the sign of a few near-zero
-    ReLU inputs, which moves single entries of the FFN w_1 gradients (max-norm) but not the tensors (L2)."""
+  * whole network: the GATE is the fp64 oracle that rounds to bf16 wherever the kernels round, forward AND backward
+    (oracle/ltr_encoder_oracle.py, bf16=True, round_bwd=True) -- what is left between the two is summation order and the
+    rounding decisions that summation order flips.  That second part is MEASURED, not assumed: the same oracle is run with
+    fp32 instead of fp64 accumulation and its deviation from itself (`self-noise`) is what a correct implementation with
+    another summation order shows on that network (0.074 max-norm on one bias gradient of the three-block slate-256 golden,
+    below 1e-2 on the others).  Bars per parameter tensor, on max(its own scale, 5 % of the case's largest gradient entry):
+        max-norm  <= max(2e-2, 4 x self-noise)        L2 <= max(1.5e-2, 2 x self-noise (L2))
+    (the max over up to 262 144 entries of two draws of the same noise differs by more than the L2 norm does: factor 4 vs 2;
+    the floors are what a network WITHOUT any flipped rounding shows: 1.6e-2 / 1.0e-2 on the two-block slate-12 golden)
+        cosine    >= 1 - max(1e-3, 2 x (1 - self cosine))   and   | |got| / |want| - 1 |  <=  max(2e-2, 2 x self)
+    (cosine / norm ratio on tensors that are not noise: own max >= 5 % of the case's largest entry);  scores 1e-2.
+    The comparison with the reference's fp32 goldens (tests/golden/encoder.npz, encoder_c5.npz) is recorded in the parity
+    ledger and sanity-checked only: scores / loss 3e-2, cosine of the whole gradient > 0.99 -- the bf16-operand arithmetic
+    BASELINE config 5 asks for, NOT the 1e-5 bar of the fp32 rows."""
 import math
 
 import numpy as np
 import pytest
 import torch
 
-from conftest import golden, ledger_record, relerr
+from conftest import golden, ledger_record, relerr, seeded_state_dict
 
 pytestmark = pytest.mark.gpu
 
@@ -217,7 +223,10 @@ def test_attention_fwd_bwd(enc, B, S, h, dk, p):
     mask = torch.zeros(B, S, dtype=torch.uint8, device=DEV)
     mask[0, S - S // 4:] = 1
     ctx = torch.empty(T, d, dtype=torch.int16, device=DEV)
-    check(lib().ltr_enc_attention_fwd(_ptr(bits(qkv)), _ptr(mask), B, S, h, dk, p, seed, sid, _ptr(ctx), _stream()), "fwd")
+    # (operand temporaries are held in names: a tensor created inside the argument list is freed -- and its block handed to
+    #  the next allocation -- before the asynchronous launch has read it)
+    qkv16 = bits(qkv)
+    check(lib().ltr_enc_attention_fwd(_ptr(qkv16), _ptr(mask), B, S, h, dk, p, seed, sid, _ptr(ctx), _stream()), "fwd")
     keep = enc.attn_dropout_mask(seed, sid, B, S, h, p, DEV).double() if p else None
     if p:
         assert abs(float(keep.mean()) - (1 - p)) < 0.02
@@ -228,7 +237,8 @@ def test_attention_fwd_bwd(enc, B, S, h, dk, p):
     dctx = rnd(T, d)
     want.backward(dctx)
     dqkv = torch.empty(T, 3 * d, dtype=torch.int16, device=DEV)
-    check(lib().ltr_enc_attention_bwd(_ptr(bits(qkv)), _ptr(ctx), _ptr(bits(dctx)), _ptr(mask), B, S, h, dk, p, seed, sid, _ptr(dqkv),
+    dctx16 = bits(dctx)
+    check(lib().ltr_enc_attention_bwd(_ptr(qkv16), _ptr(ctx), _ptr(dctx16), _ptr(mask), B, S, h, dk, p, seed, sid, _ptr(dqkv),
                                       _stream()), "bwd")
     got = unbits(dqkv)
     for j, name in enumerate("qkv"):
@@ -243,13 +253,14 @@ def test_attention_without_mask_and_all_masked_slate(enc):
     d, T = h * dk, B * S
     qkv = rnd(T, 3 * d)
     ctx = torch.empty(T, d, dtype=torch.int16, device=DEV)
-    check(lib().ltr_enc_attention_fwd(_ptr(bits(qkv)), None, B, S, h, dk, 0.0, 0, 0, _ptr(ctx), _stream()), "fwd")
+    qkv16 = bits(qkv)
+    check(lib().ltr_enc_attention_fwd(_ptr(qkv16), None, B, S, h, dk, 0.0, 0, 0, _ptr(ctx), _stream()), "fwd")
     q, k, v = (qkv[:, j * d:(j + 1) * d].view(B, S, h, dk).transpose(1, 2) for j in range(3))
     want = _attention_ref(q, k, v, torch.zeros(B, 1, 1, S, dtype=torch.bool, device=DEV), None, 0.0, dk).transpose(1, 2).reshape(T, d)
     assert err(unbits(ctx), want) < 1e-2
     mask = torch.zeros(B, S, dtype=torch.uint8, device=DEV)
     mask[1] = 1                                  # the reference yields NaN for this slate; the kernel yields zeros (header)
-    check(lib().ltr_enc_attention_fwd(_ptr(bits(qkv)), _ptr(mask), B, S, h, dk, 0.0, 0, 0, _ptr(ctx), _stream()), "fwd")
+    check(lib().ltr_enc_attention_fwd(_ptr(qkv16), _ptr(mask), B, S, h, dk, 0.0, 0, 0, _ptr(ctx), _stream()), "fwd")
     got = unbits(ctx).view(B, S, d)
     assert err(got[0], want.view(B, S, d)[0]) < 1e-2 and float(got[1].abs().max()) == 0.0
 
@@ -297,10 +308,54 @@ def _build(case, g):
     return net.to(DEV), sd
 
 
+def _oracle_gate(got, scores, sd, x, mask, cfg, y, keep=None, what="", loss_fn=None, want_dx=False, out_post=None):
+    """Compare the output / parameter gradients of the HIP path with the rounding-faithful fp64 oracle at bars derived from
+    the oracle's own fp32-vs-fp64 deviation (module docstring).  `loss_fn(out, dtype)`: the objective (default: approxNDCG
+    against y).  Every tensor is measured first, then the bars are asserted (the message lists all offenders).  Returns the
+    ledger numbers."""
+    import ltr_encoder_oracle as EO
+    import ltr_oracle as O
+    res = {}
+    for dt in (torch.float64, torch.float32):
+        fn = (lambda s_, dt=dt: loss_fn(s_, dt)) if loss_fn is not None else (lambda s_, dt=dt: O.approx_ndcg(s_, y.cpu().to(dt)))
+        res[dt] = EO.scores_and_grads(sd, x.cpu(), None if mask is None else mask.cpu(), cfg, fn, keep=keep, bf16=True, round_bwd=True,
+                                      dtype=dt, want_dx=want_dx)
+    s_o, _, g_o = res[torch.float64]
+    g_o = {k: v.double() for k, v in g_o.items()}
+    g_n = {k: v.double() for k, v in res[torch.float32][2].items()}
+    if out_post is not None:
+        s_o = out_post(s_o)
+    e_s = relerr(scores.detach().cpu().numpy(), s_o.numpy())
+    assert e_s < 1e-2, (what, "output", e_s)
+    gmax = max(float(v.abs().max()) for v in g_o.values())
+    out = dict(max=0.0, l2=0.0, noise_max=0.0, noise_l2=0.0, min_cos=1.0, scores=e_s)
+    bad = []
+    cos = lambda a_, b_: float(a_.flatten() @ b_.flatten() / max(float(a_.norm() * b_.norm()), 1e-300))      # noqa: E731
+    for k, want in g_o.items():
+        g, n = got[k].double().reshape(want.shape), g_n[k]
+        e_max, n_max = _gerr(g, want, gmax), _gerr(n, want, gmax)
+        e_l2, n_l2 = _l2err(g, want, gmax), _l2err(n, want, gmax)
+        if e_max > max(2e-2, 4 * n_max):
+            bad.append((k, "max-norm", e_max, "self-noise", n_max))
+        if e_l2 > max(1.5e-2, 2 * n_l2):
+            bad.append((k, "L2", e_l2, "self-noise", n_l2))
+        if float(want.abs().max()) >= 0.05 * gmax:
+            c, cn = cos(g, want), cos(n, want)
+            r, rn = float(g.norm() / want.norm()), float(n.norm() / want.norm())
+            if c < 1 - max(1e-3, 2 * (1 - cn)):
+                bad.append((k, "cosine", c, "self", cn))
+            if abs(r - 1) > max(2e-2, 2 * abs(rn - 1)):
+                bad.append((k, "norm ratio", r, "self", rn))
+            out["min_cos"] = min(out["min_cos"], c)
+        out.update(max=max(out["max"], e_max), l2=max(out["l2"], e_l2), noise_max=max(out["noise_max"], n_max),
+                   noise_l2=max(out["noise_l2"], n_l2))
+    assert not bad, (what, bad)
+    return out
+
+
 @pytest.mark.parametrize("case", golden("encoder").cases, ids=lambda c: c["id"])
 def test_network_vs_reference_golden(case):
     import ltr_encoder_oracle as EO
-    import ltr_oracle as O
     from losses.approxNDCG import approxNDCGLoss
     g = golden("encoder")
     net, sd = _build(case, g)
@@ -312,36 +367,81 @@ def test_network_vs_reference_golden(case):
     assert scores.shape == (case["B"], case["S"])
     loss = approxNDCGLoss(scores, y)
     loss.backward()
+    got = {k: p.grad.cpu().double() for k, p in net.named_parameters()}
+    # (1) the gate: the rounding-faithful oracle at measured-noise bars
+    cfg = EO.config_of(dict(fc_model=case["fc_model"], transformer=case["transformer"]), case["n_features"])
+    gate = _oracle_gate(got, scores, sd, x, mask, cfg, y, what=case["id"])
+    # (2) the reference's fp32 goldens: ledger + sanity
     want_s = g.arr(case, "scores")
     assert relerr(scores.detach().cpu().numpy(), want_s) < 3e-2
     assert abs(float(loss) - float(g.arr(case, "loss"))) < 3e-2 * abs(float(g.arr(case, "loss")))
-    got = {k: p.grad.cpu().double() for k, p in net.named_parameters()}
-    # (1) vs the reference's fp32 gradients: bf16 rounding flips the sign of a few ReLU pre-activations near zero, which
-    # moves single FFN units' gradients by O(1) in these small nets -- so: direction of the whole gradient + a loose
-    # per-tensor bound here, and the tight per-tensor bound against the oracle that rounds where the kernels round (2)
     ref = {k: torch.from_numpy(g.arr(case, "g/" + k)).double() for k in case["keys"]}
     gmax = max(float(v.abs().max()) for v in ref.values())
     flat_got, flat_ref = torch.cat([got[k].flatten() for k in ref]), torch.cat([ref[k].flatten() for k in ref])
     cos = float(flat_got @ flat_ref / (flat_got.norm() * flat_ref.norm()))
     assert cos > 0.99, cos
-    loose = {k: _gerr(got[k], ref[k], gmax) for k in ref}
-    assert max(loose.values()) < 0.35, {k: v for k, v in loose.items() if v >= 0.35}
-    # (2) same rounding points in the oracle's forward (straight-through in its fp64 backward)
+    loose = max(_gerr(got[k], ref[k], gmax) for k in ref)
+    note = "bf16-operand network (BASELINE config 5): bars are the bf16 ones stated in tests/test_encoder_gpu.py, not 1e-5"
+    ledger_record("encoder worst param-grad vs rounding-faithful oracle (max-norm)", gate["max"], noise=gate["noise_max"],
+                  tol=max(2e-2, 4 * gate["noise_max"]), note=note + f"; min cosine {gate['min_cos']:.6f}")
+    ledger_record("encoder worst param-grad vs rounding-faithful oracle (L2)", gate["l2"], noise=gate["noise_l2"],
+                  tol=max(1.5e-2, 2 * gate["noise_l2"]), note=note)
+    ledger_record("encoder scores vs reference fp32 (ledger only)", relerr(scores.detach().cpu().numpy(), want_s), tol=3e-2, note=note)
+    ledger_record("encoder worst param-grad vs reference fp32 (ledger only, not a gate)", loose, tol=1.0,
+                  note=note + f"; whole-gradient cosine {cos:.5f}")
+
+
+def test_benched_config5_network_vs_reference_golden():
+    """The network bench.py / tools/bench_encoder.py time for BASELINE config 5 (FC 136 -> 128, 6 blocks, 8 heads, d_ff 2048,
+    slate 256: fused-FFN kernels at 16 chunks, XCD-remapped attention), end to end against the reference."""
+    import copy
+    import ltr_encoder_oracle as EO
+    from architeture.multiLayer import make_model
+    from losses.approxNDCG import approxNDCGLoss
+    g = golden("encoder_c5")
+    case = g.cases[0]
+    net = make_model(fc_model=copy.deepcopy(case["fc_model"]), transformer=copy.deepcopy(case["transformer"]),
+                     post_model=dict(d_output=1, output_activation=None), n_features=case["n_features"])
+    assert [[k, list(v.shape)] for k, v in net.state_dict().items()] == case["shapes"]
+    sd = seeded_state_dict(case["shapes"], case["weight_seed"])
+    net.load_state_dict(sd)
+    net = net.to(DEV).eval()
+    from ltr_mi355x import encoder as enc_mod
+    assert enc_mod.fused_ffn_enabled(128, 2048)
+    x, y = torch.from_numpy(g.arr(case, "x")).to(DEV), torch.from_numpy(g.arr(case, "y")).to(DEV)
+    mask = torch.from_numpy(g.arr(case, "mask")).to(DEV)
+    scores = net(x, mask, None)
+    loss = approxNDCGLoss(scores, y)
+    loss.backward()
+    got = {k: p.grad.cpu().double() for k, p in net.named_parameters()}
     cfg = EO.config_of(dict(fc_model=case["fc_model"], transformer=case["transformer"]), case["n_features"])
-    yc = torch.from_numpy(g.arr(case, "y")).double()
-    s_o, l_o, g_o = EO.scores_and_grads(sd, torch.from_numpy(g.arr(case, "x")), None if mask is None else mask.cpu(), cfg,
-                                        lambda s: O.approx_ndcg(s, yc), bf16=True)
-    assert relerr(scores.detach().cpu().numpy(), s_o.numpy()) < 1e-2
-    gmax = max(float(v.abs().max()) for v in g_o.values())
-    tight = {k: _gerr(got[k], g_o[k], gmax) for k in g_o}
-    assert max(tight.values()) < 0.15, {k: v for k, v in tight.items() if v >= 0.15}
-    l2 = {k: _l2err(got[k], g_o[k], gmax) for k in g_o}
-    assert max(l2.values()) < 5e-2, {k: v for k, v in l2.items() if v >= 5e-2}
-    note = "bf16-operand network (BASELINE config 5): bar is the bf16 one stated in this file, not 1e-5"
-    ledger_record("encoder scores vs reference fp32", relerr(scores.detach().cpu().numpy(), want_s), tol=3e-2, note=note)
-    ledger_record("encoder worst param-grad vs reference fp32", max(loose.values()), tol=0.35, note=note + f"; cosine {cos:.5f}")
-    ledger_record("encoder worst param-grad vs bf16-rounding oracle (max-norm)", max(tight.values()), tol=0.15, note=note)
-    ledger_record("encoder worst param-grad vs bf16-rounding oracle (L2)", max(l2.values()), tol=5e-2, note=note)
+    gate = _oracle_gate(got, scores, sd, x, mask, cfg, y, what=case["id"])
+    # the reference's own numbers: scores, loss, every vector gradient in full, of every matrix gradient 4 rows + norm + sum
+    e_s = relerr(scores.detach().cpu().numpy(), g.arr(case, "scores"))
+    assert e_s < 3e-2
+    assert abs(float(loss) - float(g.arr(case, "loss"))) < 3e-2 * abs(float(g.arr(case, "loss")))
+    gmax = max([float(np.abs(g.arr(case, "g/" + k)).max()) for k, sh in case["shapes"] if len(sh) == 1] +
+               [float(g.arr(case, "gstat/" + k)[2]) for k, sh in case["shapes"] if len(sh) == 2])
+    worst, worst_norm = 0.0, 0.0
+    for k, sh in case["shapes"]:
+        if len(sh) == 1:
+            ref = torch.from_numpy(g.arr(case, "g/" + k)).double()
+            gk = got[k]
+        else:
+            ref = torch.from_numpy(g.arr(case, "grows/" + k)).double()
+            gk = got[k][:4]
+            nrm = float(g.arr(case, "gstat/" + k)[0])
+            worst_norm = max(worst_norm, abs(float(got[k].norm()) - nrm) / max(nrm, 0.05 * gmax * math.sqrt(got[k].numel())))
+        worst = max(worst, _gerr(gk, ref, gmax))
+    note = "benched config-5 network (3.6 M parameters) vs the reference's fp32 CPU run; bf16 bars (tests/test_encoder_gpu.py)"
+    assert worst_norm < 5e-2, worst_norm
+    ledger_record("config-5 network scores vs reference fp32", e_s, tol=3e-2, note=note)
+    ledger_record("config-5 network worst param-grad vs reference fp32 (stored rows; ledger only)", worst, tol=1.0, note=note)
+    ledger_record("config-5 network worst matrix-gradient norm deviation vs reference fp32", worst_norm, tol=5e-2, note=note)
+    ledger_record("config-5 network worst param-grad vs rounding-faithful oracle (max-norm)", gate["max"], noise=gate["noise_max"],
+                  tol=max(2e-2, 4 * gate["noise_max"]), note=note + f"; min cosine {gate['min_cos']:.6f}")
+    ledger_record("config-5 network worst param-grad vs rounding-faithful oracle (L2)", gate["l2"], noise=gate["noise_l2"],
+                  tol=max(1.5e-2, 2 * gate["noise_l2"]), note=note)
 
 
 def _l2err(a, b, gmax):
@@ -384,15 +484,10 @@ def test_network_train_mode_dropout_matches_oracle_under_exported_masks(enc):
         keep[("ffn_out", l)] = enc.dropout_mask(seed, enc.stream_ffn_out(l), T * d, 0.1, DEV).view(T, d).cpu()
     sd = {k: v.detach().cpu() for k, v in net.state_dict().items()}
     cfg = EO.config_of(dict(fc_model=fc, transformer=tr), F)
-    import ltr_oracle as O
-    yc = y.cpu().double()
-    s_o, _, g_o = EO.scores_and_grads(sd, x.cpu(), mask.cpu(), cfg, lambda s: O.approx_ndcg(s, yc), keep=keep, bf16=True)
-    assert relerr(scores.detach().cpu().numpy(), s_o.numpy()) < 1e-2
-    gmax = max(float(v.abs().max()) for v in g_o.values())
-    worst = {k: _gerr(p.grad.cpu().double(), g_o[k], gmax) for k, p in net.named_parameters()}
-    assert max(worst.values()) < 0.15, {k: v for k, v in worst.items() if v >= 0.15}
-    l2 = {k: _l2err(p.grad.cpu().double(), g_o[k], gmax) for k, p in net.named_parameters()}
-    assert max(l2.values()) < 5e-2, {k: v for k, v in l2.items() if v >= 5e-2}
+    got = {k: p.grad.cpu().double() for k, p in net.named_parameters()}
+    gate = _oracle_gate(got, scores, sd, x, mask, cfg, y, keep=keep, what="train-mode dropout")
+    ledger_record("encoder train-mode worst param-grad vs rounding-faithful oracle under exported masks (max-norm)", gate["max"],
+                  noise=gate["noise_max"], tol=max(2e-2, 4 * gate["noise_max"]), note="bf16 bars, tests/test_encoder_gpu.py")
     # a second training forward draws new masks; eval mode is deterministic and mask-free
     s2 = net(x, mask, None)
     assert not torch.equal(s2, scores)
@@ -415,7 +510,7 @@ def test_network_api_errors_and_features(enc):
     feats = net.prepare_for_output(x, mask, None)
     assert feats.shape == (2, 10, 16)
     w, b = net.output_layer.w_1.weight.detach(), net.output_layer.w_1.bias.detach()
-    assert relerr((feats @ w.t() + b).squeeze(2).cpu().numpy(), net.score(x, mask, None).detach().cpu().numpy()) < 1e-5
+    assert relerr((feats.detach() @ w.t() + b).squeeze(2).cpu().numpy(), net.score(x, mask, None).detach().cpu().numpy()) < 1e-5
     fc_only = make_model(dict(sizes=[32, 8], input_norm=False, activation=None, dropout=0.0), None, dict(d_output=1), 16).to(DEV)
     s = fc_only(x, None, None)                  # no encoder: mask may be None (main_batch_execution.py:124)
     assert s.shape == (2, 10)

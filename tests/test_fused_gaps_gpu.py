@@ -169,3 +169,38 @@ def test_python_scheme_helpers(dev):
             continue
         assert got.device.type == "cuda"
         assert relerr(torch.broadcast_to(got, (B, S, S)).cpu().numpy(), torch.broadcast_to(ref, (B, S, S)).numpy()) < 1e-6, name
+
+
+@pytest.mark.parametrize("kind,n_docs,train", [("double", 5 * 512 + 37, True), ("double", 1000, False), ("triple", 3 * 250, False)])
+def test_saved_activation_backward_is_bit_identical_to_the_recomputing_backward(kind, n_docs, train, dev):
+    """ltr_mlp_forward_save + ltr_mlp_backward_saved (ONE forward: h1 / h2 written by the forward launch and read back) vs
+    ltr_mlp_forward + ltr_mlp_backward (forward recomputed inside the backward launch): same arithmetic on the same values,
+    so scores and every gradient partial agree bit for bit -- incl. a ragged last tile and train-mode dropout."""
+    from ltr_mi355x import lib, scorer
+    from ltr_mi355x.functional import _ptr, _stream, check
+    net, _ = _make(kind, dev, 23)
+    h = lib()
+    info = scorer.NetInfo.get(net._ltr_net)
+    packed = scorer.pack_params(net._ltr_net, net._ltr_params())
+    gen = torch.Generator().manual_seed(n_docs)
+    x = torch.randn(n_docs, info.F, generator=gen).to(dev)
+    ds = torch.randn(n_docs, generator=gen).to(dev)
+    grid = scorer.cu_count(dev)
+    seed = 0x1234ABCD5678EF01
+    s_a, s_b = torch.empty(n_docs, device=dev), torch.empty(n_docs, device=dev)
+    p_a = torch.zeros(grid * info.partial_floats, device=dev)
+    p_b = torch.zeros(grid * info.partial_floats, device=dev)
+    n_acts = int(h.ltr_mlp_acts_floats(net._ltr_net, n_docs))
+    assert n_acts > 0 and n_acts % 256 == 0
+    acts = torch.empty(n_acts, device=dev)
+    check(h.ltr_mlp_forward(net._ltr_net, _ptr(x), n_docs, _ptr(packed), int(train), seed, None, None, _ptr(s_a), grid, _stream()), "fwd")
+    check(h.ltr_mlp_backward(net._ltr_net, _ptr(x), n_docs, _ptr(packed), int(train), seed, None, None, _ptr(ds), _ptr(p_a), grid, _stream()), "bwd")
+    check(h.ltr_mlp_forward_save(net._ltr_net, _ptr(x), n_docs, _ptr(packed), int(train), seed, None, None, _ptr(s_b), _ptr(acts), grid,
+                                 _stream()), "fwd_save")
+    check(h.ltr_mlp_backward_saved(net._ltr_net, _ptr(x), n_docs, _ptr(packed), int(train), _ptr(acts), _ptr(ds), _ptr(p_b), grid,
+                                   _stream()), "bwd_saved")
+    torch.cuda.synchronize()
+    assert torch.equal(s_a, s_b)
+    n_wg = min(grid, (n_docs + 127) // 128)
+    assert torch.equal(p_a[:n_wg * info.partial_floats], p_b[:n_wg * info.partial_floats])
+    assert float(p_a.abs().max()) > 0

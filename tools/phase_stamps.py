@@ -8,6 +8,7 @@ sys.path.insert(0, os.path.join(ROOT, "nn-with-pytorch-personalized-losses_amd")
 from architeture.doubleLayer import DoubleLayerNet  # noqa: E402
 from architeture.tripleLayer import TripleLayerNet  # noqa: E402
 from ltr_mi355x import lib, scorer  # noqa: E402
+from ltr_mi355x.extra_nets import TwoLayerNet  # noqa: E402
 from ltr_mi355x.functional import _ptr, _stream, check  # noqa: E402
 
 NAMES = ["barrier+X load->LDS", "fc1 (+act)", "fc2 (+act)", "fc3+scores", "loss", "L2 prefetch+dw3+dz2",
@@ -17,7 +18,7 @@ B, S = 25_000, 128
 X = torch.randn(B, S, 136, device=dev)
 y = torch.randint(0, 5, (B, S), device=dev).float()
 h = lib()
-for name, cls in (("double", DoubleLayerNet), ("triple", TripleLayerNet)):
+for name, cls in (("double", DoubleLayerNet), ("triple", TripleLayerNet), ("two64", TwoLayerNet)):
     net = cls(136).to(dev).eval()
     info = scorer.NetInfo.get(net._ltr_net)
     packed = scorer.pack_params(net._ltr_net, net._ltr_params())
