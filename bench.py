@@ -133,18 +133,18 @@ def self_launch(n):
 
 def secondary_lines(a):
     """Second lines measured by CHILD processes with the same shapes (never exec from this GPU-touched process):
-      bf16x3 : the split-precision variant of the pipeline (same C ABI, LTR_LIB) on the headline workload -- reported next to
-               the exact-fp32 headline, not instead of it;
+      f16x2  : the f16 x 2 split-precision variant of the pipeline (same C ABI, LTR_LIB; parity-green at the fp32 bars) on the
+               headline workload -- reported next to the exact-fp32 headline, not instead of it;
       two64  : the 136-64-1 two-layer scorer BASELINE.json configs[0] names, the configuration the 60 % HBM target was
                written for (exact-fp32 library);
       config5: BASELINE.json configs[4] -- architeture/transformer.py scorer (make_model: FC 136->128, 6 encoder blocks,
                8 heads, d_ff 2048, dropout 0.1) + approxNDCG, slate 256, bf16 operands (tools/bench_encoder.py)."""
     import subprocess
     here = os.path.abspath(__file__)
-    variant = os.path.join(ROOT, "nn-with-pytorch-personalized-losses_amd", "ltr_mi355x", "libltr_mi355x_bf16x3.so")
+    variant = os.path.join(ROOT, "nn-with-pytorch-personalized-losses_amd", "ltr_mi355x", "libltr_mi355x_f16x2.so")
     base = [sys.executable, here, "--steps", str(a.steps), "--warmup", str(a.warmup), "--queries", str(a.queries), "--slate",
             str(a.slate), "--batch", str(a.batch), "--no-cpu-baseline", "--no-extras"]
-    runs = {"bf16x3": (base + ["--net", "double"], {"LTR_LIB": variant} if os.path.exists(variant) else None),
+    runs = {"f16x2": (base + ["--net", "double"], {"LTR_LIB": variant} if os.path.exists(variant) else None),
             "two64": (base + ["--net", "two64"], {})}
     out = {}
     for name, (cmd, env_add) in runs.items():

@@ -165,7 +165,7 @@ enum { LTR_NET_DOUBLE = 0, LTR_NET_TRIPLE = 1,         /* 136 input features (MS
        LTR_NET_TWO_LAYER_64H = 4 };  /* 136 -> 64 -> 1, ReLU: the commented-out two-Linear DoubleLayerNet variant of
                                         architeture/doubleLayer.py:38-51 (BASELINE.json configs[0]); benchmark use.  No fc2:
                                         W2 / b2 are NULL in ltr_mlp_pack and the flat gradient is [W1 | b1 | w3 | b3].
-                                        (exact-fp32 library only; the bf16x3 variant rejects it with LTR_ERR_PARAM) */
+                                        */
 enum { LTR_LOSS_APPROXNDCG = 0, LTR_LOSS_LISTNET = 1 };
 
 /* info[0..7] = F, H1, H2, n_params, packed_floats, partial_floats (per workgroup), docs_per_tile, lds_bytes */
@@ -173,6 +173,15 @@ int ltr_net_info(int net, int32_t *info);
 
 int ltr_mlp_pack(int net, const float *W1, const float *b1, const float *W2, const float *b2, const float *w3,
                  const float *b3, float *packed, void *stream);
+/* Narrower networks on a compiled geometry (the reference's constructors take any input size: DoubleLayerNet(input_size) is
+ * input_size -> input_size -> input_size -> 1, doubleLayer.py:55-60; TripleLayerNet(N_features) is N_features -> 64 -> 32 -> 1,
+ * tripleLayer.py:6-10): f / h1 / h2 are the LOGICAL widths of the parameter tensors handed in (W1 [h1][f], W2 [h2][h1], w3 [h2]),
+ * each <= the compiled width; the padded inputs / hidden units get zero weights.  The caller pads X rows with zeros to the
+ * compiled feature count.  ltr_mlp_reduce_grads_sub writes the flat gradient in the LOGICAL layout
+ * [W1 (h1*f) | b1 (h1) | W2 (h2*h1) | b2 (h2) | w3 (h2) | b3 (1)]. */
+int ltr_mlp_pack_sub(int net, int f, int h1, int h2, const float *W1, const float *b1, const float *W2, const float *b2,
+                     const float *w3, const float *b3, float *packed, void *stream);
+int ltr_mlp_reduce_grads_sub(int net, int f, int h1, int h2, const float *partials, int grid, float *flat_grad, void *stream);
 
 /* Scorer forward: scores[n_docs] = net(X).  dropout != 0 applies training-mode Dropout(0.5) after each ReLU
  * (doubleLayer.py:60-65) from the counter-based stream (seed, document, feature); keep1/keep2, when non-NULL,
@@ -200,7 +209,7 @@ int ltr_mlp_reduce_grads(int net, const float *partials, int grid, float *flat_g
  * features), ltr_mlp_backward_saved reads them back instead of recomputing fc1 / fc2 (the backward kernel is bound by the
  * fp32 matrix pipe, the round trip costs HBM bandwidth it does not use).  Used for slate lengths the one-launch fused
  * step does not cover (BASELINE config 3: slate 512).  `dropout` only selects the ReLU-dropout slope (2) of the backward.
- * Exact-fp32 library only (the split-precision variant returns LTR_ERR_PARAM). */
+ */
 int64_t ltr_mlp_acts_floats(int net, int64_t n_docs);      /* < 0: LTR_ERR_* */
 int ltr_mlp_forward_save(int net, const float *X, int64_t n_docs, const float *packed, int dropout, uint64_t seed,
                          const uint8_t *keep1, const uint8_t *keep2, float *scores, float *acts, int grid, void *stream);

@@ -821,7 +821,7 @@ constexpr int kTileElems = BM * LDK;   // == BK * LDM == 9216 bf16
 static_assert(BM * LDK == BK * LDM && BM == BN, "both image shapes share one buffer size");
 constexpr size_t kGemmLds = (size_t)4 * kTileElems * sizeof(bf16_t);   // A, B double-buffered
 
-// ds_read_b64_tr_b16 (see ltr_bf16_split.h tr_frag): fragment of row tile t (16 rows of the GEMM's m / n axis) over
+// ds_read_b64_tr_b16: fragment of row tile t (16 rows of the GEMM's m / n axis) over
 // the 32 k rows starting at r0 of a [k][LD] image: lane (i = lane & 15, g = lane >> 4) gets row 16 t + i at
 // k = r0 + 4 g + {0..3} and r0 + 16 + 4 g + {0..3}.
 template <int LD>

@@ -26,22 +26,20 @@
 #include <math.h>
 #include <stdlib.h>
 
-// LTR_SPLIT_BF16 = 1 builds the split-precision variant of the slate pipeline behind the SAME C ABI
-// (libltr_mi355x_bf16x3.so): every fp32 GEMM operand is split into three bf16 pieces and multiplied on
-// v_mfma_f32_16x16x32_bf16 with fp32 accumulation (6 of the 9 piece products: error ~2^-24, i.e. fp32-level),
-// see ltr_pipeline_bf16x3.h.  Default (0): exact fp32 on v_mfma_f32_16x16x4_f32.
-#ifndef LTR_SPLIT_BF16
-#define LTR_SPLIT_BF16 0
-#endif
 
 // LTR_F16X2 = 1 builds the f16 x 2 split variant (libltr_mi355x_f16x2.so, same C ABI): fc1 / fc2 / dh1 -- the GEMMs whose
 // B operand lives in the wave's registers -- run on v_mfma_f32_16x16x32_f16 with every fp32 operand split into two f16
-// pieces (hi + lo, power-of-two pre-scaling per document / per weight matrix) and THREE of the four piece products
-// (hi hi, hi lo, lo hi; the dropped lo lo term is 2^-22 of the product) accumulated in fp32; the weight-gradient GEMMs stay on
-// the exact fp32 instruction.  4 B per element like fp32, 16/3 = 5.3 x the fp32 matrix rate.  See DESIGN.md section 4.3.
+// pieces (hi + lo, power-of-two pre-scaling per document / per weight matrix / running maximum) and the piece products
+// (hi hi, hi lo, lo hi and -- LTR_LOLO -- lo lo) accumulated in fp32; the weight-gradient GEMMs run the same way on f16 image
+// pairs staged in LDS.  4 B per element like fp32, 16/4 = 4 x the fp32 matrix rate.  See DESIGN.md section 4.3.
 #ifndef LTR_F16X2
 #define LTR_F16X2 0
 #endif
+#ifndef LTR_LOLO
+#define LTR_LOLO 1               // 1: all FOUR piece products (the lo lo term too): the product of the split operands is then exact and
+#endif                           //    the error is the operands' 2^-22 representation alone.  The matrix pipe has the slack (the FC GEMMs
+                                 //    are bound by weight-fragment bandwidth, the dW GEMMs by LDS latency); with three products the
+                                 //    cancelling bias gradients of a 48-document golden missed the 1e-5 bar by 6 %.
 
 using namespace ltr;
 
@@ -67,7 +65,6 @@ __host__ __device__ constexpr bool x_reg_prefetch() { return MODE == 0 /*MODE_FW
 enum { ACT_ID = 0, ACT_RELU_DROP = 1, ACT_SIGMOID = 2 };
 enum { MODE_FWD = 0, MODE_BWD = 1, MODE_FUSED = 2, MODE_BWD_SAVED = 3 };   // BWD_SAVED: h1 / h2 read back, not recomputed
 
-#if !LTR_SPLIT_BF16
 // TWO_: a two-Linear-layer scorer  w3 . act1(W1 x + b1) + b3  (no fc2: the commented-out 136-64-1 DoubleLayerNet variant of
 // doubleLayer.py:38-51, BASELINE.json configs[0]).  Declared with H2 = H1 and A2 = A1: "h2" is then h1 itself, the
 // backward through fc3 yields dz1 directly, and the fc2 / dh1 / dW2 GEMMs are compiled out.
@@ -113,20 +110,13 @@ struct NetT {
     static_assert(F % 4 == 0 && H1 % 4 == 0 && H2 % 4 == 0, "feature counts must be multiples of 4");
     static_assert(NT1 % BH1 == 0 && NT2 % BH2 == 0, "band height must divide the dW row-tile count");
 };
-#else
-#include "ltr_pipeline_bf16x3_net.h"
-#endif
 using DoubleNet = NetT<136, 136, 136, ACT_RELU_DROP, ACT_RELU_DROP, 3, 3>;   // doubleLayer.py:54-66
 using TripleNet = NetT<136, 64, 32, ACT_ID, ACT_SIGMOID, 2, 2>;              // tripleLayer.py:5-17
 // the same classes on the reference's 64-feature collection (TD2003, utils/dataset.py:23-30)
 using DoubleNet64 = NetT<64, 64, 64, ACT_RELU_DROP, ACT_RELU_DROP, 2, 2>;
 using TripleNet64 = NetT<64, 64, 32, ACT_ID, ACT_SIGMOID, 2, 2>;
-#if !LTR_SPLIT_BF16
 using TwoLayerNet64h = NetT<136, 64, 64, ACT_RELU_DROP, ACT_RELU_DROP, 2, 2, true>;   // 136 -> 64 -> 1 (bench-only)
 #define LTR_FOR_NET_EXTRA(...) case LTR_NET_TWO_LAYER_64H: { using NET = TwoLayerNet64h; __VA_ARGS__; } break;
-#else
-#define LTR_FOR_NET_EXTRA(...)           /* the split-precision variant compiles the reference's live classes only */
-#endif
 
 // run the statement(s) given after `net` with NET bound to the network type of id `net` (LTR_NET_*); unknown ids ->
 // LTR_ERR_PARAM.  Variadic: the statement may contain top-level commas (kernel launches).
@@ -320,11 +310,90 @@ __device__ __forceinline__ void gemm_wx_h(__amdgpu_buffer_rsrc_t rsrc, int base_
         out[To] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ahi, bhi, out[To], 0, 0, 0);
         out[To] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ahi, blo, out[To], 0, 0, 0);
         out[To] = __builtin_amdgcn_mfma_f32_16x16x32_f16(alo, bhi, out[To], 0, 0, 0);
+        if (LTR_LOLO) out[To] = __builtin_amdgcn_mfma_f32_16x16x32_f16(alo, blo, out[To], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
     }
 #pragma unroll
     for (int To = 0; To < NT; ++To) out[To] *= un;
 }
+
+// ---- the same GEMM with the weight fragments SHARED through LDS (backward / fused kernels of the 136-wide nets).
+// Streaming them L2 -> registers per wave (gemm_wx_h) is bound by the CU's 64 B/clk vector-memory path: 8 waves x 2 KiB per
+// (k-step, tile) against 96 matrix-pipe cycles.  Here a GEMM's fragments travel ONCE per workgroup, L2 -> LDS by LDS-DMA, in
+// chunks of two k-steps (<= 36 KiB) that ping-pong between the two halves of the dW staging region (idle outside the dW
+// phases); all 8 waves read them with conflict-free ds_read_b128.  One wait + barrier per chunk: it publishes chunk c and
+// retires chunk c-1, whose buffer then receives chunk c+1 (or the next GEMM's chunk 0) while chunk c is being multiplied.
+constexpr int kWBufFloats = 9216;            // 36 KiB
+constexpr int kPPC = 2;                      // k-steps per chunk
+typedef __attribute__((address_space(1))) const void *w_gptr_t;
+typedef __attribute__((address_space(3))) void *w_lptr_t;
+
+template <int NT, int KP>
+__device__ __forceinline__ void dma_wchunk(const float *sec, int c, float *buf, int w, int lane) {
+    static_assert(kPPC * NT * 2 * 256 <= kWBufFloats, "a chunk must fit one 36 KiB buffer");
+    const int p0 = c * kPPC * NT * 2;                                          // first 1 KiB piece of the chunk
+    const int np = (KP - c * kPPC < kPPC ? KP - c * kPPC : kPPC) * NT * 2;
+    for (int i = w; i < np; i += kWaves)
+        __builtin_amdgcn_global_load_lds((w_gptr_t)(sec + (size_t)(p0 + i) * 256 + lane * 4), (w_lptr_t)(buf + i * 256), 16, 0, 0);
+}
+
+// PAR: which buffer holds chunk 0 (its DMA was ISSUED by the caller).  issue_next(buf) is called once, when the last chunk
+// has been published, with the buffer that is free from then on.
+template <int NT, int KT, int PAR, int KMAX, int NMAX, class Next>
+__device__ __forceinline__ void gemm_wx_hl(const float *sec, float *Wb, int w, int lane, const f32x4 (&bin)[KMAX],
+                                           f32x4 (&out)[NMAX], float inv_w, Next issue_next) {
+    constexpr int KP = (KT + 1) / 2;
+    constexpr int NCH = (KP + kPPC - 1) / kPPC;
+    float m = 0.f;
+#pragma unroll
+    for (int T = 0; T < KT; ++T)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) m = fmaxf(m, fabsf(bin[T][r]));
+    m = fmaxf(m, __shfl_xor(m, 16, 64));
+    m = fmaxf(m, __shfl_xor(m, 32, 64));
+    int e = __builtin_amdgcn_frexp_expf(m);
+    e = e < -100 ? -100 : e;
+    const float sc = ldexpf(1.f, 14 - e);
+    const float un = ldexpf(inv_w, e - 14);
+#pragma unroll
+    for (int To = 0; To < NT; ++To) out[To] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        float *nb = Wb + (((PAR + c + 1) & 1) ? kWBufFloats : 0);
+        if (c + 1 < NCH) dma_wchunk<NT, KP>(sec, c + 1, nb, w, lane);
+        else issue_next(nb);
+        const float *cb = Wb + (((PAR + c) & 1) ? kWBufFloats : 0) + lane * 4;
+#pragma unroll
+        for (int Pl = 0; Pl < kPPC; ++Pl) {
+            const int P = c * kPPC + Pl;
+            if (P < KP) {
+                h16x8 bhi, blo;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int T = 2 * P + (j >> 2);
+                    const float v = (T < KT ? bin[T < KT ? T : 0][j & 3] : 0.f) * sc;
+                    const _Float16 h = (_Float16)v;
+                    bhi[j] = h;
+                    blo[j] = (_Float16)(v - (float)h);
+                }
+#pragma unroll
+                for (int To = 0; To < NT; ++To) {
+                    const h16x8 ahi = __builtin_bit_cast(h16x8, *reinterpret_cast<const f32x4 *>(cb + ((Pl * NT + To) * 2) * 256));
+                    const h16x8 alo = __builtin_bit_cast(h16x8, *reinterpret_cast<const f32x4 *>(cb + ((Pl * NT + To) * 2 + 1) * 256));
+                    out[To] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ahi, bhi, out[To], 0, 0, 0);
+                    out[To] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ahi, blo, out[To], 0, 0, 0);
+                    out[To] = __builtin_amdgcn_mfma_f32_16x16x32_f16(alo, bhi, out[To], 0, 0, 0);
+                    if (LTR_LOLO) out[To] = __builtin_amdgcn_mfma_f32_16x16x32_f16(alo, blo, out[To], 0, 0, 0);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int To = 0; To < NT; ++To) out[To] *= un;
+}
+
 #endif
 
 // Activation (+ dropout) on accumulator tiles; features >= H forced to 0 (only the partial last tile needs it).
@@ -506,31 +575,167 @@ __device__ __forceinline__ void dw_chunk(int w, f32x4 (&acc)[TW], const float *a
     }
 }
 
+#if LTR_F16X2
+// ---- step 3: the weight-gradient GEMMs dW = dz^T [h | 1] on the f16 matrix cores as well.
+// Both operands are staged in LDS as f16 hi / lo IMAGES [document][feature] (2 x 2 B per element = the bytes of the fp32
+// staging they replace) and read k-major (k = document) with the transposing ds_read_b64_tr_b16.  The contraction runs
+// over documents, so an operand's power-of-two scale must be the same for every document of a launch-long accumulation:
+// each operand carries a RUNNING-MAX exponent (it only grows; when it grows, the wave multiplies its dW accumulators by
+// the matching power of two -- exact -- before adding the tile).  X itself lives in LDS as such an image pair from the
+// moment it lands, and serves fc1 (B operand, read row-wise) and dW1 (read k-major) alike.
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 h16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+
+// fragment of feature tile t (16 features: lane & 15) over the 32 documents from r0 of a [document][LDH] image; lane
+// (i, g) gets documents r0 + 4g + {0..3} and r0 + 16 + 4g + {0..3} -- the same k-slot order for both operands.
+// lane_base = img + (4 g + (i >> 2)) * LDH + 4 (i & 3).  EXEC must be full.
+template <int LDH>
+__device__ __forceinline__ h16x8 tr_frag_h(const uint16_t *lane_base, int r0, int t) {
+    typedef __attribute__((address_space(3))) s16x4 *lp4;
+    const uint16_t *p = lane_base + r0 * LDH + 16 * t;
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp4)(p));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp4)(p + 16 * LDH));
+    const u32x2 l2 = __builtin_bit_cast(u32x2, lo), h2 = __builtin_bit_cast(u32x2, hi);
+    return __builtin_bit_cast(h16x8, u32x4{l2[0], l2[1], h2[0], h2[1]});
+}
+
+// 4 fp32 values -> scaled hi / lo f16 quads (8 bytes each)
+__device__ __forceinline__ void split4(const f32x4 &v, float sc, u32x2 &hi, u32x2 &lo) {
+    h16x4 h, l;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const float x = v[r] * sc;
+        h[r] = (_Float16)x;
+        l[r] = (_Float16)(x - (float)h[r]);
+    }
+    hi = __builtin_bit_cast(u32x2, h);
+    lo = __builtin_bit_cast(u32x2, l);
+}
+
+// dW tiles of wave W += A^T B over KS k-steps of 32 documents; A / B: lane bases of the hi and lo images.  The wave's row
+// fragments stay resident for a k-step, its columns are walked one at a time.  Scheduling is left to hipcc: pinning every
+// column's [reads][MFMAs] with scheduling barriers and software-pipelining the column reads by hand were both measured
+// slower (5.25 / 5.48 vs 4.77 ms per step, profiles/r03_variant_ab.json).
+template <int W, int TW, int NR, int NC, int BH, int LDH, int KS>
+__device__ __forceinline__ void dw_chunk_h_w(f32x4 (&acc)[TW], const uint16_t *ahi, const uint16_t *alo, const uint16_t *bhi,
+                                             const uint16_t *blo) {
+    using S = DwSet<W, TW, NR, NC, BH>;
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+        h16x8 ah[NR], al[NR];
+#pragma unroll
+        for (int To = 0; To < NR; ++To)
+            if (S::uses_row(To)) {
+                ah[To] = tr_frag_h<LDH>(ahi, 32 * s, To);
+                al[To] = tr_frag_h<LDH>(alo, 32 * s, To);
+            }
+#pragma unroll
+        for (int Ti = 0; Ti < NC; ++Ti)
+            if (S::uses_col(Ti)) {
+                const h16x8 bh = tr_frag_h<LDH>(bhi, 32 * s, Ti), bl = tr_frag_h<LDH>(blo, 32 * s, Ti);
+#pragma unroll
+                for (int j = 0; j < TW; ++j) {
+                    const int g = W * TW + j;
+                    if (g < NR * NC && dw_col<NR, NC, BH>(g) == Ti) {
+                        const int r = dw_row<NR, NC, BH>(g);
+                        acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[r], bh, acc[j], 0, 0, 0);
+                        acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[r], bl, acc[j], 0, 0, 0);
+                        acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[r], bh, acc[j], 0, 0, 0);
+                        if (LTR_LOLO) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[r], bl, acc[j], 0, 0, 0);
+                    }
+                }
+            }
+    }
+}
+
+template <int TW, int NR, int NC, int BH, int LDH, int KS>
+__device__ __forceinline__ void dw_chunk_h(int w, f32x4 (&acc)[TW], const uint16_t *ahi, const uint16_t *alo, const uint16_t *bhi,
+                                           const uint16_t *blo) {
+    switch (w) {   // wave-uniform: one specialised, branch-free body per wave (full EXEC for the transposing reads)
+        case 0: dw_chunk_h_w<0, TW, NR, NC, BH, LDH, KS>(acc, ahi, alo, bhi, blo); break;
+        case 1: dw_chunk_h_w<1, TW, NR, NC, BH, LDH, KS>(acc, ahi, alo, bhi, blo); break;
+        case 2: dw_chunk_h_w<2, TW, NR, NC, BH, LDH, KS>(acc, ahi, alo, bhi, blo); break;
+        case 3: dw_chunk_h_w<3, TW, NR, NC, BH, LDH, KS>(acc, ahi, alo, bhi, blo); break;
+        case 4: dw_chunk_h_w<4, TW, NR, NC, BH, LDH, KS>(acc, ahi, alo, bhi, blo); break;
+        case 5: dw_chunk_h_w<5, TW, NR, NC, BH, LDH, KS>(acc, ahi, alo, bhi, blo); break;
+        case 6: dw_chunk_h_w<6, TW, NR, NC, BH, LDH, KS>(acc, ahi, alo, bhi, blo); break;
+        default: dw_chunk_h_w<7, TW, NR, NC, BH, LDH, KS>(acc, ahi, alo, bhi, blo); break;
+    }
+}
+
+// fc1 with B read from the X image pair (uniform scale): out^T tiles = W x X^T for this lane's document row.
+template <int NT, int KT, int LDH, int NMAX>
+__device__ __forceinline__ void gemm_wx_hx(__amdgpu_buffer_rsrc_t rsrc, int base_bytes, int lane_off, const uint16_t *xhi_row,
+                                           const uint16_t *xlo_row, f32x4 (&out)[NMAX], float un) {
+    constexpr int KP = (KT + 1) / 2;
+    constexpr int NSTEP = KP * NT, NLOAD = 2 * NSTEP, R = LTR_RING_H;
+    f32x4 ring[R];
+#pragma unroll
+    for (int n = 0; n < R; ++n)
+        if (n < NLOAD) ring[n] = load_frag(rsrc, lane_off, base_bytes + n * 1024);
+#pragma unroll
+    for (int To = 0; To < NT; ++To) out[To] = f32x4{0.f, 0.f, 0.f, 0.f};
+    h16x8 bhi, blo;
+#pragma unroll
+    for (int n = 0; n < NSTEP; ++n) {
+        const int P = n / NT, To = n % NT;
+        if (To == 0) {
+            const u32x2 z = {0u, 0u};
+            const u32x2 h0 = *reinterpret_cast<const u32x2 *>(xhi_row + 32 * P), l0 = *reinterpret_cast<const u32x2 *>(xlo_row + 32 * P);
+            const u32x2 h1 = 2 * P + 1 < KT ? *reinterpret_cast<const u32x2 *>(xhi_row + 32 * P + 16) : z;
+            const u32x2 l1 = 2 * P + 1 < KT ? *reinterpret_cast<const u32x2 *>(xlo_row + 32 * P + 16) : z;
+            bhi = __builtin_bit_cast(h16x8, u32x4{h0[0], h0[1], h1[0], h1[1]});
+            blo = __builtin_bit_cast(h16x8, u32x4{l0[0], l0[1], l1[0], l1[1]});
+        }
+        const h16x8 ahi = __builtin_bit_cast(h16x8, ring[(2 * n) % R]);
+        const h16x8 alo = __builtin_bit_cast(h16x8, ring[(2 * n + 1) % R]);
+        if (2 * n + R < NLOAD) ring[(2 * n) % R] = load_frag(rsrc, lane_off, base_bytes + (2 * n + R) * 1024);
+        if (2 * n + 1 + R < NLOAD) ring[(2 * n + 1) % R] = load_frag(rsrc, lane_off, base_bytes + (2 * n + 1 + R) * 1024);
+        out[To] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ahi, bhi, out[To], 0, 0, 0);
+        out[To] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ahi, blo, out[To], 0, 0, 0);
+        out[To] = __builtin_amdgcn_mfma_f32_16x16x32_f16(alo, bhi, out[To], 0, 0, 0);
+        if (LTR_LOLO) out[To] = __builtin_amdgcn_mfma_f32_16x16x32_f16(alo, blo, out[To], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int To = 0; To < NT; ++To) out[To] *= un;
+}
+
+// running-max exponent of a staged operand: ex such that max|v| * 2^(14 - ex) stays below 2^14
+__device__ __forceinline__ int grow_exp(int ex, float m) {
+    int e = __builtin_amdgcn_frexp_expf(m);
+    e = m > 0.f ? e : -100;
+    e = e < -100 ? -100 : e;
+    return e > ex ? e : ex;
+}
+#endif
+
 // accumulator tiles of wave W -> workgroup partial (row = 4q + r, col = lane & 15)
 template <int W, int TW, int NR, int NC, int BH>
-__device__ __forceinline__ void dw_store_w(const f32x4 (&acc)[TW], float *dst, int q, int d) {
+__device__ __forceinline__ void dw_store_w(const f32x4 (&acc)[TW], float *dst, int q, int d, float scale) {
 #pragma unroll
     for (int j = 0; j < TW; ++j) {
         const int g = W * TW + j;
         if (g < NR * NC) {
             const int To = dw_row<NR, NC, BH>(g), Ti = dw_col<NR, NC, BH>(g);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) dst[(16 * To + 4 * q + r) * (NC * 16) + 16 * Ti + d] = acc[j][r];
+            for (int r = 0; r < 4; ++r) dst[(16 * To + 4 * q + r) * (NC * 16) + 16 * Ti + d] = acc[j][r] * scale;
         }
     }
 }
 
 template <int TW, int NR, int NC, int BH>
-__device__ __forceinline__ void dw_store(int w, const f32x4 (&acc)[TW], float *dst, int q, int d) {
+__device__ __forceinline__ void dw_store(int w, const f32x4 (&acc)[TW], float *dst, int q, int d, float scale = 1.f) {
     switch (w) {
-        case 0: dw_store_w<0, TW, NR, NC, BH>(acc, dst, q, d); break;
-        case 1: dw_store_w<1, TW, NR, NC, BH>(acc, dst, q, d); break;
-        case 2: dw_store_w<2, TW, NR, NC, BH>(acc, dst, q, d); break;
-        case 3: dw_store_w<3, TW, NR, NC, BH>(acc, dst, q, d); break;
-        case 4: dw_store_w<4, TW, NR, NC, BH>(acc, dst, q, d); break;
-        case 5: dw_store_w<5, TW, NR, NC, BH>(acc, dst, q, d); break;
-        case 6: dw_store_w<6, TW, NR, NC, BH>(acc, dst, q, d); break;
-        default: dw_store_w<7, TW, NR, NC, BH>(acc, dst, q, d); break;
+        case 0: dw_store_w<0, TW, NR, NC, BH>(acc, dst, q, d, scale); break;
+        case 1: dw_store_w<1, TW, NR, NC, BH>(acc, dst, q, d, scale); break;
+        case 2: dw_store_w<2, TW, NR, NC, BH>(acc, dst, q, d, scale); break;
+        case 3: dw_store_w<3, TW, NR, NC, BH>(acc, dst, q, d, scale); break;
+        case 4: dw_store_w<4, TW, NR, NC, BH>(acc, dst, q, d, scale); break;
+        case 5: dw_store_w<5, TW, NR, NC, BH>(acc, dst, q, d, scale); break;
+        case 6: dw_store_w<6, TW, NR, NC, BH>(acc, dst, q, d, scale); break;
+        default: dw_store_w<7, TW, NR, NC, BH>(acc, dst, q, d, scale); break;
     }
 }
 
@@ -591,7 +796,6 @@ __device__ __forceinline__ void dma_x_rows(const PipeArgs &a, float *Xs, long lo
     }
 }
 
-#if !LTR_SPLIT_BF16
 template <class N, int MODE, int LOSS>
 __global__ void __launch_bounds__(kThreads, 2) slate_pipeline_kernel(const PipeArgs a) {
     constexpr int LD = N::LD;
@@ -643,7 +847,41 @@ __global__ void __launch_bounds__(kThreads, 2) slate_pipeline_kernel(const PipeA
 
     constexpr bool XPREF = x_reg_prefetch<N, MODE>();
     constexpr bool XDMA = LTR_XDMA && !XPREF;
+#if LTR_F16X2
+#ifndef LTR_WLDS
+#define LTR_WLDS 0               // 1: fc1 / fc2 / dh1 weight fragments shared through LDS (gemm_wx_hl; A/B: no faster than L2 streaming)
+#endif
+#ifndef LTR_DWH
+#define LTR_DWH 1                // 1: the weight-gradient GEMMs on the f16 matrix cores too (step 3)
+#endif
+    constexpr bool DWH = LTR_DWH && MODE != MODE_FWD && (XDMA || XPREF);
+    constexpr bool WLDS = LTR_WLDS && !DWH && N::H1 > 64 && MODE != MODE_FWD && XDMA;
+    float *Wb = Ds;                                                    // two 36 KiB buffers = the dW staging region
+    static_assert(!WLDS || 2 * kWBufFloats <= 2 * kChunkDocs * N::LD, "the two weight buffers live in the dW staging region");
+    constexpr int LDH = LD;                                            // halfs per row of an f16 image (LD / 2 dwords: 8 mod 64 at LD = 144)
+    uint16_t *Xhi = reinterpret_cast<uint16_t *>(Xs), *Xlo = Xhi + kTileDocs * LDH;   // X as hi / lo images: the bytes of the fp32 tile
+    uint16_t *Sg = reinterpret_cast<uint16_t *>(Ds);                   // staging images (and the landing zone of the X DMA)
+    float *exch = scratch + kThreads + 4 * 32;                         // [64] per-wave maxima, exchanged at barriers that exist anyway
+    int exx = 1, exh = 1, exd2 = -100, exd1 = -100, E1 = -400, E2 = -400;   // running-max exponents (>= 1 where a ones feature rides along)
+    float w3max = 0.f;
+#else
+    constexpr bool DWH = false;
+    constexpr bool WLDS = false;
+#endif
     f32x4 xn[kXV4<N>()];
+#if LTR_F16X2
+    if (DWH) {    // zero pad columns of both X images (the ones feature at column F is rewritten per tile: it carries the scale)
+        for (int e = tid; e < kTileDocs * (LD - N::F); e += kThreads) {
+            const int r = e / (LD - N::F), c = N::F + e % (LD - N::F);
+            Xhi[r * LDH + c] = 0;
+            Xlo[r * LDH + c] = 0;
+        }
+        __syncthreads();                                   // w3s is complete
+        float m = 0.f;
+        for (int j = lane; j < N::NT2 * 16; j += 64) m = fmaxf(m, fabsf(w3s[j]));
+        w3max = wave_allmax(m);
+    } else
+#endif
     if (XDMA) {   // pad columns of the X tile (ones feature at column F, zeros up to LD): constant, written once
         constexpr int PADV4 = (LD - N::F) / 4;
         for (int e = tid; e < kTileDocs * PADV4; e += kThreads) {
@@ -668,11 +906,70 @@ __global__ void __launch_bounds__(kThreads, 2) slate_pipeline_kernel(const PipeA
         const int crow = 16 * (w & 3) + d;
         const int lane_off = lane * 16;
         const int tid = 64 * w + lane;
+#if LTR_F16X2
+        // this wave's 16 rows (held in xn) -> hi / lo images, once the tile's scale is known (all 8 wave maxima published)
+        auto convert_x = [&]() {
+            float xm = 1.f;                                // the ones feature
+#pragma unroll
+            for (int i = 0; i < kWaves; ++i) xm = fmaxf(xm, exch[i]);
+            exx = grow_exp(exx, xm);
+            const float sx = ldexpf(1.f, 14 - exx);
+            constexpr int V4_PER_ROW = N::F / 4, V4 = 16 * V4_PER_ROW;
+#pragma unroll
+            for (int mm = 0; mm < kXV4<N>(); ++mm) {
+                const int e = lane + 64 * mm;
+                if (e < V4) {
+                    u32x2 hi, lo;
+                    split4(xn[mm], sx, hi, lo);
+                    const int off = (16 * w + e / V4_PER_ROW) * LDH + 4 * (e % V4_PER_ROW);
+                    *reinterpret_cast<u32x2 *>(Xhi + off) = hi;
+                    *reinterpret_cast<u32x2 *>(Xlo + off) = lo;
+                }
+            }
+            if (lane < 16) {
+                Xhi[(16 * w + lane) * LDH + N::F] = __builtin_bit_cast(uint16_t, (_Float16)sx);
+                Xlo[(16 * w + lane) * LDH + N::F] = 0;
+            }
+        };
+        auto publish_xmax = [&]() {
+            float m = 0.f;
+#pragma unroll
+            for (int mm = 0; mm < kXV4<N>(); ++mm)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) m = fmaxf(m, fabsf(xn[mm][r]));
+            m = wave_allmax(m);
+            if (lane == 0) exch[w] = m;
+        };
+        if (DWH && XPREF) {   // register-prefetch kernels: the slice is in xn already (first tile: fetched here), its max goes out
+            if (st == (int)blockIdx.x) load_x_tile<N>(xn, a, doc_base + 16 * w, lane);      // before the barrier below
+            publish_xmax();
+        }
+#endif
         LTR_STAMP(0)
         __syncthreads();   // previous super-tile done with Xs / sc / dsc
         // ---- X: HBM -> LDS, coalesced 16 B per lane; the wave's 16 documents are contiguous in memory.
+#if LTR_F16X2
+        if (DWH && XPREF) {
+            convert_x();
+        } else if (DWH) {
+            // X lands as fp32 in the (idle) staging region; every wave takes ITS 16 rows into registers and publishes their max
+            dma_x_rows<N>(a, Ds, doc_base + 16 * w, w, lane);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            constexpr int V4_PER_ROW = N::F / 4, V4 = 16 * V4_PER_ROW;
+#pragma unroll
+            for (int mm = 0; mm < kXV4<N>(); ++mm) {
+                const int e = lane + 64 * mm;
+                xn[mm] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (e < V4) xn[mm] = *reinterpret_cast<const f32x4 *>(Ds + (16 * w + e / V4_PER_ROW) * LD + 4 * (e % V4_PER_ROW));
+            }
+            publish_xmax();
+        } else
+#endif
         if (XDMA) {
             dma_x_rows<N>(a, Xs, doc_base + 16 * w, w, lane);
+#if LTR_F16X2
+            if (WLDS && MODE != MODE_BWD_SAVED) dma_wchunk<N::NT1, N::KP1>(a.packed + N::W1H_OFF, 0, Wb, w, lane);   // fc1 chunk 0
+#endif
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         } else {
             // register-prefetch kernels: only the first tile is loaded here, later ones arrive ahead of time
@@ -707,6 +1004,9 @@ __global__ void __launch_bounds__(kThreads, 2) slate_pipeline_kernel(const PipeA
             dsc[tid] = doc < a.n_docs ? a.dscores_in[doc] : 0.f;
         }
         __syncthreads();
+#if LTR_F16X2
+        if (DWH && !XPREF) convert_x();   // the tile's scale is known now (read back by this wave in fc1, by all waves in dW1)
+#endif
 
         LTR_STAMP(1)
         const long long gdoc = doc_base + my_row;
@@ -729,14 +1029,26 @@ __global__ void __launch_bounds__(kThreads, 2) slate_pipeline_kernel(const PipeA
 #pragma unroll
             for (int T = 0; T < N::NT2; ++T)
                 h2[T] = N::TWO ? h1[T] : *reinterpret_cast<const f32x4 *>(a.acts_in + act_base + (size_t)(N::NT1 + T) * 256);
-        } else {
+        }
+#if LTR_F16X2
+        else if (DWH) {
+            if (N::H1T > N::NT1) h1[N::H1T - 1] = f32x4{0.f, 0.f, 0.f, 0.f};
+            gemm_wx_hx<N::NT1, N::XT, LDH>(wrsrc, N::W1H_OFF * 4, lane_off, Xhi + my_row * LDH + 4 * q, Xlo + my_row * LDH + 4 * q, h1,
+                                           ldexpf(w3s[N::NT2 * 16 + 4], exx - 14));
+        }
+#endif
+        else {
             f32x4 xb[N::XT];
 #pragma unroll
             for (int T = 0; T < N::XT; ++T)
                 xb[T] = *reinterpret_cast<const f32x4 *>(Xs + my_row * LD + 16 * T + 4 * q);
             if (N::H1T > N::NT1) h1[N::H1T - 1] = f32x4{0.f, 0.f, 0.f, 0.f};
 #if LTR_F16X2
-            if (!LTR_SKIP(a, 16)) gemm_wx_h<N::NT1, N::XT>(wrsrc, N::W1H_OFF * 4, lane_off, xb, h1, w3s[N::NT2 * 16 + 4]);
+            if (WLDS)
+                gemm_wx_hl<N::NT1, N::XT, 0>(a.packed + N::W1H_OFF, Wb, w, lane, xb, h1, w3s[N::NT2 * 16 + 4], [&](float *nb) {
+                    if (!N::TWO) dma_wchunk<N::NT2, N::KP2>(a.packed + N::W2H_OFF, 0, nb, w, lane);                 // fc2 chunk 0
+                });
+            else if (!LTR_SKIP(a, 16)) gemm_wx_h<N::NT1, N::XT>(wrsrc, N::W1H_OFF * 4, lane_off, xb, h1, w3s[N::NT2 * 16 + 4]);
 #else
             if (!LTR_SKIP(a, 16)) gemm_wx<N::NT1, N::XT>(wrsrc, N::W1F_OFF * 4, lane_off, xb, h1);
 #endif
@@ -753,6 +1065,17 @@ __global__ void __launch_bounds__(kThreads, 2) slate_pipeline_kernel(const PipeA
             constexpr int Tn = N::H1 / 16, p = N::H1 % 16;
             h1[Tn][p % 4] = (q == p / 4) ? 1.f : h1[Tn][p % 4];
         }
+#if LTR_F16X2
+        if (DWH) {
+            float m = 0.f;
+#pragma unroll
+            for (int T = 0; T < N::NT1; ++T)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) m = fmaxf(m, fabsf(h1[T][r]));
+            m = wave_allmax(m);
+            if (lane == 0) exch[8 + w] = m;
+        }
+#endif
         LTR_STAMP(2)
         // ---- fc2
         if (saved) {
@@ -761,7 +1084,10 @@ __global__ void __launch_bounds__(kThreads, 2) slate_pipeline_kernel(const PipeA
             for (int To = 0; To < N::NT2; ++To) h2[To] = h1[To];
         } else {
 #if LTR_F16X2
-            if (!LTR_SKIP(a, 8)) gemm_wx_h<N::NT2, N::H1T>(wrsrc, N::W2H_OFF * 4, lane_off, h1, h2, w3s[N::NT2 * 16 + 5]);
+            if (WLDS)      // chunk 0 sits in the buffer fc1's last chunk left free: (0 + NCH1) & 1
+                gemm_wx_hl<N::NT2, N::H1T, ((N::KP1 + kPPC - 1) / kPPC) & 1>(a.packed + N::W2H_OFF, Wb, w, lane, h1, h2, w3s[N::NT2 * 16 + 5],
+                                                                            [&](float *) {});
+            else if (!LTR_SKIP(a, 8)) gemm_wx_h<N::NT2, N::H1T>(wrsrc, N::W2H_OFF * 4, lane_off, h1, h2, w3s[N::NT2 * 16 + 5]);
 #else
             if (!LTR_SKIP(a, 8)) gemm_wx<N::NT2, N::H1T>(wrsrc, N::W2F_OFF * 4, lane_off, h1, h2);
 #endif
@@ -816,10 +1142,10 @@ __global__ void __launch_bounds__(kThreads, 2) slate_pipeline_kernel(const PipeA
                 ApproxScratch xs;               // enables the no-clamp path (4 pair terms per v_rcp, histogram ideal DCG)
                 xs.um = xt + so;
                 if (a.S == 128)
-                    loss = approx_ndcg_slate<32>(g, sc + so, yl + so, gn + so, gg + so, uu + so, mk + so, a.alpha,
+                    loss = approx_ndcg_slate<32, (N::H1 <= 64 ? 4 : 2)>(g, sc + so, yl + so, gn + so, gg + so, uu + so, mk + so, a.alpha,
                                                  a.eps, a.gscale, true, st_ds, stamp_fn, xs);
                 else if (a.S == 64)
-                    loss = approx_ndcg_slate<16>(g, sc + so, yl + so, gn + so, gg + so, uu + so, mk + so, a.alpha,
+                    loss = approx_ndcg_slate<16, (N::H1 <= 64 ? 4 : 2)>(g, sc + so, yl + so, gn + so, gg + so, uu + so, mk + so, a.alpha,
                                                  a.eps, a.gscale, true, st_ds, NoStamp(), xs);
                 else
                     loss = approx_ndcg_slate<8>(g, sc + so, yl + so, gn + so, gg + so, uu + so, mk + so, a.alpha,
@@ -889,6 +1215,49 @@ __global__ void __launch_bounds__(kThreads, 2) slate_pipeline_kernel(const PipeA
         }
 #endif
         LTR_STAMP(6)
+#if LTR_F16X2
+        if (DWH && !N::TWO) {
+            // operand scales of dW2 (running maxima): h1 from the per-wave maxima published before the loss barrier; dz2 from
+            // the bound |dz2| <= |d score| slope max|w3| (the scores' gradients are LDS-resident: every wave takes their max)
+            float hm = 1.f;
+#pragma unroll
+            for (int i = 0; i < kWaves; ++i) hm = fmaxf(hm, exch[8 + i]);
+            exh = grow_exp(exh, hm);
+            const float dm = wave_allmax(fmaxf(fabsf(dsc[lane]), fabsf(dsc[lane + 64])));
+            exd2 = grow_exp(exd2, dm * slope * w3max);
+            if (exd2 + exh != E2) {                        // the scale grew: bring the accumulators along (exact: a power of two)
+                const float f = ldexpf(1.f, E2 - (exd2 + exh));
+#pragma unroll
+                for (int n = 0; n < N::TW2; ++n) accW2[n] *= f;
+                E2 = exd2 + exh;
+            }
+            const float sd = ldexpf(1.f, 14 - exd2), sh = ldexpf(1.f, 14 - exh);
+            const int lb = (4 * q + (d >> 2)) * LDH + 4 * (d & 3);          // lane base of the transposing reads
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                if (c > 0) __syncthreads();   // chunk 0 fully consumed
+                if (chunk == c) {             // images of this 64-document chunk: dz2 hi | dz2 lo | h1 hi | h1 lo, [64][LDH] each
+#pragma unroll
+                    for (int To = 0; To < N::NT2; ++To) {
+                        u32x2 hi, lo;
+                        split4(h2[To], sd, hi, lo);
+                        *reinterpret_cast<u32x2 *>(Sg + crow * LDH + 16 * To + 4 * q) = hi;
+                        *reinterpret_cast<u32x2 *>(Sg + (64 + crow) * LDH + 16 * To + 4 * q) = lo;
+                    }
+#pragma unroll
+                    for (int T = 0; T < N::H1T; ++T) {
+                        u32x2 hi, lo;
+                        split4(h1[T], sh, hi, lo);
+                        *reinterpret_cast<u32x2 *>(Sg + (128 + crow) * LDH + 16 * T + 4 * q) = hi;
+                        *reinterpret_cast<u32x2 *>(Sg + (192 + crow) * LDH + 16 * T + 4 * q) = lo;
+                    }
+                }
+                __syncthreads();
+                dw_chunk_h<N::TW2, N::NT2, N::H1T, N::BH2, LDH, 2>(w, accW2, Sg + lb, Sg + 64 * LDH + lb, Sg + 128 * LDH + lb,
+                                                                   Sg + 192 * LDH + lb);
+            }
+        } else
+#endif
         // ---- dW2 += dz2^T [h1 | 1] over the two 64-document chunks (tiles of waves 0-3, then waves 4-7)
 #pragma unroll
         for (int c = 0; c < (N::TWO ? 0 : 2); ++c) {
@@ -926,7 +1295,11 @@ __global__ void __launch_bounds__(kThreads, 2) slate_pipeline_kernel(const PipeA
             for (int To = 0; To < N::NT1; ++To) dz1[To] = h2[To];
         }
 #if LTR_F16X2
-        else if (!LTR_SKIP(a, 4)) gemm_wx_h<N::NT1, N::NT2>(wrsrc, N::W2TH_OFF * 4, lane_off, h2, dz1, w3s[N::NT2 * 16 + 6]);
+        else if (WLDS) {
+            __syncthreads();                       // every wave is done reading Ds / Hs (dW2 chunk 1): the region is free
+            dma_wchunk<N::NT1, N::KPT>(a.packed + N::W2TH_OFF, 0, Wb, w, lane);
+            gemm_wx_hl<N::NT1, N::NT2, 0>(a.packed + N::W2TH_OFF, Wb, w, lane, h2, dz1, w3s[N::NT2 * 16 + 6], [&](float *) {});
+        } else if (!LTR_SKIP(a, 4)) gemm_wx_h<N::NT1, N::NT2>(wrsrc, N::W2TH_OFF * 4, lane_off, h2, dz1, w3s[N::NT2 * 16 + 6]);
 #else
         else if (!LTR_SKIP(a, 4)) gemm_wx<N::NT1, N::NT2>(wrsrc, N::W2T_OFF * 4, lane_off, h2, dz1);
 #endif
@@ -949,6 +1322,42 @@ __global__ void __launch_bounds__(kThreads, 2) slate_pipeline_kernel(const PipeA
                 dz1[To][r] = v;
             }
         LTR_STAMP(8)
+#if LTR_F16X2
+        if (DWH) {
+            float m = 0.f;
+#pragma unroll
+            for (int To = 0; To < N::NT1; ++To)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) m = fmaxf(m, fabsf(dz1[To][r]));
+            m = wave_allmax(m);
+            if (lane == 0) exch[16 + w] = m;
+            __syncthreads();              // every wave is done reading the dW2 images; the dz1 maxima are published
+            float dm = 0.f;
+#pragma unroll
+            for (int i = 0; i < kWaves; ++i) dm = fmaxf(dm, exch[16 + i]);
+            exd1 = grow_exp(exd1, dm);
+            if (exd1 + exx != E1) {
+                const float f = ldexpf(1.f, E1 - (exd1 + exx));
+#pragma unroll
+                for (int n = 0; n < N::TW1; ++n) accW1[n] *= f;
+                E1 = exd1 + exx;
+            }
+            const float sd = ldexpf(1.f, 14 - exd1);
+#pragma unroll
+            for (int To = 0; To < N::NT1; ++To) {          // dz1 of all 128 documents: hi image | lo image, [128][LDH] each
+                u32x2 hi, lo;
+                split4(dz1[To], sd, hi, lo);
+                *reinterpret_cast<u32x2 *>(Sg + my_row * LDH + 16 * To + 4 * q) = hi;
+                *reinterpret_cast<u32x2 *>(Sg + (128 + my_row) * LDH + 16 * To + 4 * q) = lo;
+            }
+            __syncthreads();
+            // next super-tile's X slice -> registers now (register-prefetch kernels); it lands during the dW1 MFMAs below
+            if (XPREF && st + (int)gridDim.x < a.n_super)
+                load_x_tile<N>(xn, a, (long long)(st + gridDim.x) * kTileDocs + 16 * w, lane);
+            const int lb = (4 * q + (d >> 2)) * LDH + 4 * (d & 3);
+            dw_chunk_h<N::TW1, N::NT1, N::XT, N::BH1, LDH, 4>(w, accW1, Sg + lb, Sg + 128 * LDH + lb, Xhi + lb, Xlo + lb);
+        } else {
+#endif
         // next super-tile's X slice -> registers now (h1/h2 are dead); it lands during the dW1 MFMAs below
         if (MODE != MODE_FWD && XPREF && st + (int)gridDim.x < a.n_super)
             load_x_tile<N>(xn, a, (long long)(st + gridDim.x) * kTileDocs + 16 * w, lane);
@@ -990,6 +1399,9 @@ __global__ void __launch_bounds__(kThreads, 2) slate_pipeline_kernel(const PipeA
                                                                 Xs + (64 * c + q) * LD + d);
             }
         }
+#if LTR_F16X2
+        }
+#endif
         LTR_STAMP(9)
         asm volatile("" ::"v"(pf));   // keep the prefetch load alive (and waited for) until here
     }
@@ -997,8 +1409,13 @@ __global__ void __launch_bounds__(kThreads, 2) slate_pipeline_kernel(const PipeA
     if (MODE == MODE_FWD) return;
     // ---- per-workgroup partial gradients -> workspace
     float *part = a.partials + (size_t)blockIdx.x * N::PART;
-    dw_store<N::TW1, N::NT1, N::XT, N::BH1>(w, accW1, part + N::P_W1, q, d);
-    if (!N::TWO) dw_store<N::TW2, N::NT2, N::H1T, N::BH2>(w, accW2, part + N::P_W2, q, d);
+#if LTR_F16X2
+    const float us1 = DWH ? ldexpf(1.f, E1 - 28) : 1.f, us2 = DWH ? ldexpf(1.f, E2 - 28) : 1.f;   // accumulators -> true scale
+#else
+    const float us1 = 1.f, us2 = 1.f;
+#endif
+    dw_store<N::TW1, N::NT1, N::XT, N::BH1>(w, accW1, part + N::P_W1, q, d, us1);
+    if (!N::TWO) dw_store<N::TW2, N::NT2, N::H1T, N::BH2>(w, accW2, part + N::P_W2, q, d, us2);
     __syncthreads();
     for (int j = tid; j < N::NT2 * 16; j += kThreads) {
         float s = 0.f;
@@ -1015,9 +1432,6 @@ __global__ void __launch_bounds__(kThreads, 2) slate_pipeline_kernel(const PipeA
     }
 }
 
-#else
-#include "ltr_pipeline_bf16x3.h"
-#endif
 
 // The keep mask the pipeline's counter-based dropout stream produces (tests / reproducibility tooling).
 __global__ void dropout_mask_kernel(unsigned long long seed, int layer, long long n_docs, int H, uint8_t *out) {
@@ -1028,17 +1442,19 @@ __global__ void dropout_mask_kernel(unsigned long long seed, int layer, long lon
     out[e] = (keep_word(seed, layer, doc, n >> 5) >> (n & 31)) & 1u;
 }
 
-#if !LTR_SPLIT_BF16
 // Pack nn.Linear parameters into lane-ordered MFMA A-fragments (once per optimizer step; 37k params).
 template <class N>
 __global__ void pack_kernel(const float *__restrict__ W1, const float *__restrict__ b1, const float *__restrict__ W2,
                             const float *__restrict__ b2, const float *__restrict__ w3, const float *__restrict__ b3,
-                            float *__restrict__ packed) {
+                            float *__restrict__ packed, int Fr, int H1r, int H2r) {
+    // Fr / H1r / H2r: the LOGICAL layer widths (<= the compiled N::F / N::H1 / N::H2): a narrower network runs zero-padded
+    // on the compiled geometry -- padded inputs and hidden units carry zero weights, so they contribute nothing, and the
+    // bias columns stay at the compiled positions N::F / N::H1.
     const int gt = blockIdx.x * blockDim.x + threadIdx.x;
     const int stride = gridDim.x * blockDim.x;
     // augmented weights: Waug[n][f] = W[n][f] (f < in), b[n] (f == in), 0 otherwise; rows n >= out are 0
-    auto w1aug = [&](int n, int f) { return n < N::H1 ? (f < N::F ? W1[n * N::F + f] : (f == N::F ? b1[n] : 0.f)) : 0.f; };
-    auto w2aug = [&](int n, int f) { return n < N::H2 ? (f < N::H1 ? W2[n * N::H1 + f] : (f == N::H1 ? b2[n] : 0.f)) : 0.f; };
+    auto w1aug = [&](int n, int f) { return n < H1r ? (f < Fr ? W1[n * Fr + f] : (f == N::F ? b1[n] : 0.f)) : 0.f; };
+    auto w2aug = [&](int n, int f) { return n < H2r ? (f < H1r ? W2[n * H1r + f] : (f == N::H1 ? b2[n] : 0.f)) : 0.f; };
     for (int e = gt; e < N::NT1 * N::XT * 256; e += stride) {
         const int s = e & 3, lane = (e >> 2) & 63, tile = e >> 8, To = tile / N::XT, T = tile - To * N::XT;
         packed[N::W1F_OFF + e] = w1aug(16 * To + (lane & 15), 16 * T + 4 * (lane >> 4) + s);
@@ -1051,7 +1467,7 @@ __global__ void pack_kernel(const float *__restrict__ W1, const float *__restric
     for (int e = gt; e < (N::TWO ? 0 : N::NT1 * N::NT2 * 256); e += stride) {
         const int s = e & 3, lane = (e >> 2) & 63, tile = e >> 8, Ti = tile / N::NT2, T = tile - Ti * N::NT2;
         const int in = 16 * Ti + (lane & 15), o = 16 * T + 4 * (lane >> 4) + s;
-        packed[N::W2T_OFF + e] = (o < N::H2 && in < N::H1) ? W2[o * N::H1 + in] : 0.f;
+        packed[N::W2T_OFF + e] = (o < H2r && in < H1r) ? W2[o * H1r + in] : 0.f;
     }
 #if LTR_F16X2
     // ---- f16 hi / lo fragments of the same three matrices, each scaled by ONE power of two so that its largest |entry| lands
@@ -1104,11 +1520,11 @@ __global__ void pack_kernel(const float *__restrict__ W1, const float *__restric
         int Ti, i, o;
         geom(hh, N::NT1, Ti, i, o);
         const int in = 16 * Ti + i;
-        put((size_t)N::W2TH_OFF * 2, hh, (o < N::H2 && in < N::H1) ? W2[o * N::H1 + in] * scl[2] : 0.f);
+        put((size_t)N::W2TH_OFF * 2, hh, (o < H2r && in < H1r) ? W2[o * H1r + in] * scl[2] : 0.f);
     }
 #endif
     for (int e = gt; e < N::NT2 * 16 + 16; e += stride) {
-        float v = e < N::H2 ? w3[e] : (e == N::NT2 * 16 ? b3[0] : 0.f);
+        float v = e < H2r ? w3[e] : (e == N::NT2 * 16 ? b3[0] : 0.f);
 #if LTR_F16X2
         if (e >= N::NT2 * 16 + 4 && e < N::NT2 * 16 + 7) v = inv[e - N::NT2 * 16 - 4];
 #endif
@@ -1116,12 +1532,11 @@ __global__ void pack_kernel(const float *__restrict__ W1, const float *__restric
     }
 }
 
-#endif
 
 // Sum the per-workgroup partials in a fixed order and scatter into the flat gradient
 // [W1 (H1 x F) | b1 (H1) | W2 (H2 x H1) | b2 (H2) | w3 (H2) | b3 (1)]  (= nn.Module parameter order).
 template <class N>
-__global__ void reduce_grads_kernel(const float *__restrict__ partials, int nparts, float *__restrict__ flat) {
+__global__ void reduce_grads_kernel(const float *__restrict__ partials, int nparts, float *__restrict__ flat, int Fr, int H1r, int H2r) {
     // 8 lanes per parameter: lane s sums partials s, s+8, s+16, ... (independent loads in flight), then the 8
     // strided sums are combined by a fixed butterfly -> same bits on every run, ~8x less serial latency.
     // The cross-workgroup sum runs in fp64 (37 k parameters x 256 partials: free) so the only fp32 rounding left
@@ -1129,18 +1544,19 @@ __global__ void reduce_grads_kernel(const float *__restrict__ partials, int npar
     const int gt = blockIdx.x * blockDim.x + threadIdx.x;
     const int e = gt >> 3, sub = gt & 7;
     double s = 0.0;
-    if (e < N::NPARAM) {
+    const int nparam = N::TWO ? H1r * Fr + H1r + H2r + 1 : H1r * Fr + H1r + H2r * H1r + H2r + H2r + 1;   // logical widths
+    if (e < nparam) {
         int off;
         int k = e;
-        if (k < N::H1 * N::F) {
-            off = N::P_W1 + (k / N::F) * (N::XT * 16) + (k % N::F);
-        } else if ((k -= N::H1 * N::F) < N::H1) {
+        if (k < H1r * Fr) {
+            off = N::P_W1 + (k / Fr) * (N::XT * 16) + (k % Fr);
+        } else if ((k -= H1r * Fr) < H1r) {
             off = N::P_W1 + k * (N::XT * 16) + N::F;
-        } else if (!N::TWO && (k -= N::H1) < N::H2 * N::H1) {
-            off = N::P_W2 + (k / N::H1) * (N::H1T * 16) + (k % N::H1);
-        } else if (!N::TWO && (k -= N::H2 * N::H1) < N::H2) {
+        } else if (!N::TWO && (k -= H1r) < H2r * H1r) {
+            off = N::P_W2 + (k / H1r) * (N::H1T * 16) + (k % H1r);
+        } else if (!N::TWO && (k -= H2r * H1r) < H2r) {
             off = N::P_W2 + k * (N::H1T * 16) + N::H1;
-        } else if ((k -= (N::TWO ? N::H1 : N::H2)) < N::H2) {
+        } else if ((k -= (N::TWO ? H1r : H2r)) < H2r) {
             off = N::P_W3 + k;
         } else {
             off = N::P_B3;
@@ -1150,17 +1566,15 @@ __global__ void reduce_grads_kernel(const float *__restrict__ partials, int npar
     s += __shfl_xor(s, 1, 64);
     s += __shfl_xor(s, 2, 64);
     s += __shfl_xor(s, 4, 64);
-    if (e < N::NPARAM && sub == 0) flat[e] = (float)s;
+    if (e < nparam && sub == 0) flat[e] = (float)s;
 }
 
-#if !LTR_SPLIT_BF16
 template <class N>
 constexpr size_t pipeline_lds() {
     return sizeof(float) * (size_t)(kTileDocs * N::LD + 2 * kChunkDocs * N::LD + 8 * kTileDocs + N::NT2 * 16 + 16 +
                                     kWaves * N::NT2 * 16 + kThreads + 4 * 32 + 64);
 }
 
-#endif
 
 inline int status() {
     hipError_t e = hipGetLastError();
@@ -1189,9 +1603,7 @@ int pipeline_dispatch(int mode, const PipeArgs &a, int grid, hipStream_t stream)
     switch (mode) {
         case MODE_FWD: return launch_pipeline<N, MODE_FWD, 0>(a, grid, stream);
         case MODE_BWD: return launch_pipeline<N, MODE_BWD, 0>(a, grid, stream);
-#if !LTR_SPLIT_BF16
         case MODE_BWD_SAVED: return launch_pipeline<N, MODE_BWD_SAVED, 0>(a, grid, stream);
-#endif
         default:
             switch (a.loss_kind) {
                 case 0: return launch_pipeline<N, MODE_FUSED, 0>(a, grid, stream);
@@ -1225,14 +1637,23 @@ int ltr_dropout_keep_mask(uint64_t seed, int layer, int64_t n_docs, int H, uint8
     return status();
 }
 
-int ltr_mlp_pack(int net, const float *W1, const float *b1, const float *W2, const float *b2, const float *w3,
-                 const float *b3, float *packed, void *stream) {
+int ltr_mlp_pack_sub(int net, int f, int h1, int h2, const float *W1, const float *b1, const float *W2, const float *b2,
+                     const float *w3, const float *b3, float *packed, void *stream) {
     if (!W1 || !b1 || !w3 || !b3 || !packed) return LTR_ERR_NULL;
     if ((!W2 || !b2) && net != LTR_NET_TWO_LAYER_64H) return LTR_ERR_NULL;     /* two-layer nets have no fc2 */
     if (!aligned16(packed)) return LTR_ERR_ALIGN;
-    LTR_FOR_NET(net, hipLaunchKernelGGL(pack_kernel<NET>, dim3(64), dim3(256), 0, (hipStream_t)stream, W1, b1, W2, b2, w3,
-                                        b3, packed))
+    LTR_FOR_NET(net, {
+        if (f < 1 || f > NET::F || h1 < 1 || h1 > NET::H1 || h2 < 1 || h2 > NET::H2) return LTR_ERR_SHAPE;
+        hipLaunchKernelGGL(pack_kernel<NET>, dim3(64), dim3(256), 0, (hipStream_t)stream, W1, b1, W2, b2, w3, b3, packed, f, h1, h2);
+    })
     return status();
+}
+
+int ltr_mlp_pack(int net, const float *W1, const float *b1, const float *W2, const float *b2, const float *w3,
+                 const float *b3, float *packed, void *stream) {
+    int32_t info[8];
+    if (int rc = ltr_net_info(net, info)) return rc;
+    return ltr_mlp_pack_sub(net, info[0], info[1], info[2], W1, b1, W2, b2, w3, b3, packed, stream);
 }
 
 // diagnostic builds (-DLTR_STAMPS): where the phase stamps of the next launches go (NULL: none)
@@ -1307,9 +1728,6 @@ int64_t ltr_mlp_acts_floats(int net, int64_t n_docs) {
 
 int ltr_mlp_forward_save(int net, const float *X, int64_t n_docs, const float *packed, int dropout, uint64_t seed,
                          const uint8_t *keep1, const uint8_t *keep2, float *scores, float *acts, int grid, void *stream) {
-#if LTR_SPLIT_BF16
-    return LTR_ERR_PARAM;
-#else
     PipeArgs a;
     if (int rc = fill_common(a, net, X, n_docs, packed, dropout, seed, keep1, keep2)) return rc;
     if (!scores || !acts) return LTR_ERR_NULL;
@@ -1321,14 +1739,10 @@ int ltr_mlp_forward_save(int net, const float *X, int64_t n_docs, const float *p
     if (grid > a.n_super) grid = a.n_super;
     LTR_FOR_NET(net, return pipeline_dispatch<NET>(MODE_FWD, a, grid, (hipStream_t)stream))
     return LTR_ERR_PARAM;
-#endif
 }
 
 int ltr_mlp_backward_saved(int net, const float *X, int64_t n_docs, const float *packed, int dropout, const float *acts,
                            const float *dscores, float *partials, int grid, void *stream) {
-#if LTR_SPLIT_BF16
-    return LTR_ERR_PARAM;
-#else
     PipeArgs a;
     if (int rc = fill_common(a, net, X, n_docs, packed, dropout, 0, nullptr, nullptr)) return rc;
     if (!dscores || !partials || !acts) return LTR_ERR_NULL;
@@ -1339,15 +1753,23 @@ int ltr_mlp_backward_saved(int net, const float *X, int64_t n_docs, const float 
     a.acts_in = acts;
     LTR_FOR_NET(net, return pipeline_dispatch<NET>(MODE_BWD_SAVED, a, grid, (hipStream_t)stream))
     return LTR_ERR_PARAM;
-#endif
+}
+
+int ltr_mlp_reduce_grads_sub(int net, int f, int h1, int h2, const float *partials, int grid, float *flat_grad, void *stream) {
+    if (!partials || !flat_grad) return LTR_ERR_NULL;
+    if (grid < 1) return LTR_ERR_PARAM;
+    LTR_FOR_NET(net, {
+        if (f < 1 || f > NET::F || h1 < 1 || h1 > NET::H1 || h2 < 1 || h2 > NET::H2) return LTR_ERR_SHAPE;
+        hipLaunchKernelGGL(reduce_grads_kernel<NET>, dim3((NET::NPARAM * 8 + 255) / 256), dim3(256), 0, (hipStream_t)stream, partials,
+                           grid, flat_grad, f, h1, h2);
+    })
+    return status();
 }
 
 int ltr_mlp_reduce_grads(int net, const float *partials, int grid, float *flat_grad, void *stream) {
-    if (!partials || !flat_grad) return LTR_ERR_NULL;
-    if (grid < 1) return LTR_ERR_PARAM;
-    LTR_FOR_NET(net, hipLaunchKernelGGL(reduce_grads_kernel<NET>, dim3((NET::NPARAM * 8 + 255) / 256), dim3(256), 0,
-                                        (hipStream_t)stream, partials, grid, flat_grad))
-    return status();
+    int32_t info[8];
+    if (int rc = ltr_net_info(net, info)) return rc;
+    return ltr_mlp_reduce_grads_sub(net, info[0], info[1], info[2], partials, grid, flat_grad, stream);
 }
 
 int ltr_fused_step(int net, int loss_kind, const float *X, const float *labels, int B, int S, const float *packed,

@@ -87,7 +87,7 @@ __device__ __forceinline__ void approx_ndcg_init(const SlateGroup &g) {
 // (was ~13: add, rcp = 4 slots, mul, max, fma and 5 of rank counting) and 4.3 in sweep 2 (was ~14).
 // sweep 1:  pos_i - 1 = sum_j um_j / (u_i + u_j) - 1/2 [i real]
 // sweep 2:  d loss / d s_k = alpha u_k sum_j um_j (g_j - g_k) / (u_k + u_j)^2        (t_kj = u_k u_j / (u_k + u_j)^2)
-template <int JB = 0, class Store, class Stamp = NoStamp>
+template <int JB = 0, int UNR = 2, class Store, class Stamp = NoStamp>
 __device__ __forceinline__ float approx_ndcg_slate(const SlateGroup &g, float *sc, float *yl, const float *gn,
                                                    float *gg, float *uu, float *mk, float alpha, float eps,
                                                    float gscale, bool want_grad, Store store, Stamp stamp = Stamp(),
@@ -162,7 +162,7 @@ __device__ __forceinline__ float approx_ndcg_slate(const SlateGroup &g, float *s
             if (vi) {
                 const float ui = uu[i];
                 lds_f2 acc = {0.f, 0.f};
-#pragma unroll 2
+#pragma unroll UNR
                 for (int j = j0; j < j1; j += 4) {
                     const lds_f4 u = *reinterpret_cast<const lds_f4 *>(uu + j);
                     const lds_f4 n = *reinterpret_cast<const lds_f4 *>(xs.um + j);
@@ -230,11 +230,21 @@ __device__ __forceinline__ float approx_ndcg_slate(const SlateGroup &g, float *s
         }
         const float r = ultra ? 0.f : row_reduce(g, cnt);
         const float pos = 1.f + row_reduce(g, p);
-        if (ultra && row && g.cg == 0 && cnt > 0.f) idcg_acc += cnt / log2f(2.f + (float)i);
-        if (vi && g.cg == 0) {
+        if (ultra) {
+            // per-row epilogue on the hardware transcendentals (v_log_f32 / v_rcp_f32, 1 ulp each): the IEEE log2f / division
+            // sequences of the general path are ~100 instructions per row, executed by every wave of the workgroup
+            if (row && g.cg == 0 && cnt > 0.f) idcg_acc = fmaf(cnt, __frcp_rn(__log2f(2.f + (float)i)), idcg_acc);
+            if (vi && g.cg == 0) {
+                const float gain = gn[i];
+                const float iL = __frcp_rn(__log2f(1.f + pos));
+                const float gl = gain * iL;
+                loss_acc += gl;
+                gg[i] = gl * iL * __frcp_rn((1.f + pos) * LTR_LN2);    // d(-sum gain/L)/d pos_i, not yet / maxDCG
+            }
+        } else if (vi && g.cg == 0) {
             const float gain = gn[i];
             const float L = log2f(1.f + pos);
-            if (!ultra && gain > 0.f) idcg_acc += gain / log2f(2.f + r);
+            if (gain > 0.f) idcg_acc += gain / log2f(2.f + r);
             loss_acc += gain / L;
             const float gi = gain / (L * L * (1.f + pos) * LTR_LN2);   // d(-sum gain/L)/d pos_i, not yet / maxDCG
             gg[i] = gi;
@@ -271,7 +281,7 @@ __device__ __forceinline__ float approx_ndcg_slate(const SlateGroup &g, float *s
         if (vk && ultra) {
             const float gk = gg[k], uk = uu[k];
             lds_f2 acc = {0.f, 0.f};
-#pragma unroll 2
+#pragma unroll UNR
             for (int j = j0; j < j1; j += 4) {
                 const lds_f4 u = *reinterpret_cast<const lds_f4 *>(uu + j);
                 const lds_f4 n = *reinterpret_cast<const lds_f4 *>(xs.um + j);

@@ -1,8 +1,9 @@
 """Build libltr_mi355x.so (and its split-precision variant) in-tree with hipcc for gfx950 (cross-compiles without a GPU).
 
-  libltr_mi355x.so         exact fp32 slate pipeline (v_mfma_f32_16x16x4_f32)            -- the default library
-  libltr_mi355x_bf16x3.so  same C ABI, ALL GEMMs as 3-piece bf16 splits on v_mfma_f32_16x16x32_bf16 (-DLTR_SPLIT_BF16=1);
-                           selected with LTR_LIB=<path> (ltr_mi355x._lib)
+  libltr_mi355x.so        exact fp32 slate pipeline (v_mfma_f32_16x16x4_f32)                    -- the default library
+  libltr_mi355x_f16x2.so  same C ABI; the FC scorer GEMMs of the slate pipeline as two-piece f16 splits (hi + lo, three of
+                          the four piece products) on v_mfma_f32_16x16x32_f16 with fp32 accumulation (-DLTR_F16X2=1);
+                          selected with LTR_LIB=<path> (ltr_mi355x._lib).  Only csrc/ltr_scorer.hip differs.
 """
 import glob
 import os
@@ -13,7 +14,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(os.path.dirname(HERE), "csrc")
 OUT = os.path.join(HERE, "libltr_mi355x.so")
 FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-shared", "-fPIC", "-fno-gpu-rdc"]
-VARIANTS = {"": [], "bf16x3": ["-DLTR_SPLIT_BF16=1"]}
+VARIANTS = {"": [], "f16x2": ["-DLTR_F16X2=1"]}
 
 
 def variant_path(variant=""):

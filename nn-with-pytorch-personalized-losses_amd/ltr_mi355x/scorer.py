@@ -20,11 +20,17 @@ COMPILED_FEATURES = {136: (NET_DOUBLE, NET_TRIPLE), 64: (NET_DOUBLE_64, NET_TRIP
 
 
 def net_id(kind, n_features):
-    """kind 'double' | 'triple' -> compiled network id for this input size."""
-    if n_features not in COMPILED_FEATURES:
-        raise NotImplementedError(f"the gfx950 scorer kernels are compiled for {sorted(COMPILED_FEATURES)} input "
-                                  f"features (MSLR-WEB / TD2003), got {n_features}")
-    return COMPILED_FEATURES[n_features][0 if kind == "double" else 1]
+    """kind 'double' | 'triple' -> network handle for this input size: the compiled id for 136 / 64 features (MSLR-WEB /
+    TD2003, the reference's collections), otherwise `compiled id | n_features << 8` -- the network runs zero-padded on the next
+    compiled geometry (ltr_mlp_pack_sub / ltr_mlp_reduce_grads_sub; X rows are padded by `_docs`)."""
+    n_features = int(n_features)
+    which = 0 if kind == "double" else 1
+    if n_features in COMPILED_FEATURES:
+        return COMPILED_FEATURES[n_features][which]
+    if not 1 <= n_features <= 136:
+        raise NotImplementedError(f"the gfx950 scorer kernels hold a 128-document tile of up to 136 features in LDS; "
+                                  f"input_size {n_features} is not built")
+    return COMPILED_FEATURES[64 if n_features <= 64 else 136][which] | (n_features << 8)
 LOSS_APPROXNDCG, LOSS_LISTNET, LOSS_LAMBDA = 0, 1, 2
 _MASK64 = (1 << 64) - 1
 
@@ -33,14 +39,23 @@ class NetInfo:
     """Static geometry of a compiled network (ltr_net_info)."""
     _cache = {}
 
-    def __init__(self, net):
+    def __init__(self, handle):
         buf = (ctypes.c_int32 * 8)()
-        check(lib().ltr_net_info(net, buf), "ltr_net_info")
+        self.net = handle & 0xFF                     # the compiled network the kernels run
+        check(lib().ltr_net_info(self.net, buf), "ltr_net_info")
         (self.F, self.H1, self.H2, self.n_params, self.packed_floats, self.partial_floats, self.tile_docs,
          self.lds_bytes) = list(buf)
-        self.net = net
+        self.handle = handle
+        self.cF, self.cH1, self.cH2 = self.F, self.H1, self.H2          # compiled widths (X row length the kernels read)
         # two-Linear-layer nets (no fc2) carry [W1, b1, w3, b3] only
         self.two_layer = self.n_params == self.H1 * self.F + self.H1 + self.H2 + 1
+        if handle >> 8:                              # a narrower network, zero-padded onto the compiled geometry
+            f = handle >> 8
+            self.F = f
+            if self.net in (NET_DOUBLE, NET_DOUBLE_64):
+                self.H1 = self.H2 = f                # input_size -> input_size -> input_size -> 1 (doubleLayer.py:55-60)
+            self.n_params = self.H1 * self.F + self.H1 + self.H2 * self.H1 + self.H2 + self.H2 + 1
+        self.padded = self.F != self.cF
         self.shapes = ([(self.H1, self.F), (self.H1,), (1, self.H2), (1,)] if self.two_layer else
                        [(self.H1, self.F), (self.H1,), (self.H2, self.H1), (self.H2,), (1, self.H2), (1,)])
 
@@ -90,8 +105,13 @@ def pack_params(net, params, out=None):
     ptrs = [_ptr(t) for t in ps]
     if info.two_layer:
         ptrs = ptrs[:2] + [None, None] + ptrs[2:]          # no fc2: W2 / b2 are NULL in the C ABI
-    check(lib().ltr_mlp_pack(net, *ptrs, _ptr(out), _stream()), "ltr_mlp_pack")
+    check(lib().ltr_mlp_pack_sub(info.net, info.F, info.H1, info.H2, *ptrs, _ptr(out), _stream()), "ltr_mlp_pack_sub")
     return out
+
+
+def reduce_grads(info, partials, grid, flat):
+    check(lib().ltr_mlp_reduce_grads_sub(info.net, info.F, info.H1, info.H2, _ptr(partials), grid, _ptr(flat), _stream()),
+          "ltr_mlp_reduce_grads_sub")
 
 
 def _docs(x, info):
@@ -100,6 +120,8 @@ def _docs(x, info):
     if x.dtype != torch.float32:
         raise TypeError(f"scorer kernels take fp32 features, got {x.dtype}")
     x2 = x.detach().reshape(-1, info.F)
+    if info.padded:                                  # zero-pad the rows to the compiled feature count (one extra pass over X)
+        return torch.nn.functional.pad(x2, (0, info.cF - info.F))
     if not x2.is_contiguous():
         x2 = x2.contiguous()
     if x2.data_ptr() % 16:
@@ -107,11 +129,14 @@ def _docs(x, info):
     return x2
 
 
-def _mask(m, n_docs, H):
+def _mask(m, n_docs, H, cH=None):
+    """Explicit dropout keep mask [n_docs, H] -> bytes; padded with ones to the compiled width cH."""
     if m is None:
         return None
-    m = m.detach().reshape(n_docs, H).to(torch.uint8).contiguous()
-    return m
+    m = m.detach().reshape(n_docs, H).to(torch.uint8)
+    if cH is not None and cH != H:
+        m = torch.nn.functional.pad(m, (0, cH - H), value=1)
+    return m.contiguous()
 
 
 class _MLPScores(torch.autograd.Function):
@@ -123,10 +148,10 @@ class _MLPScores(torch.autograd.Function):
             x2 = _docs(x, info)
             n = x2.shape[0]
             packed = pack_params(net, params)
-            k1, k2 = _mask(keep1, n, info.H1), _mask(keep2, n, info.H2)
+            k1, k2 = _mask(keep1, n, info.H1, info.cH1), _mask(keep2, n, info.H2, info.cH2)
             scores = torch.empty(n, dtype=torch.float32, device=dev)
             grid = default_grid(dev, n, info.tile_docs)
-            check(lib().ltr_mlp_forward(net, _ptr(x2), n, _ptr(packed), int(dropout), seed, _ptr(k1), _ptr(k2),
+            check(lib().ltr_mlp_forward(info.net, _ptr(x2), n, _ptr(packed), int(dropout), seed, _ptr(k1), _ptr(k2),
                                         _ptr(scores), grid, _stream()), "ltr_mlp_forward")
         ctx.save_for_backward(x2, packed, k1, k2)
         ctx.meta = (net, int(dropout), seed, grid, [p.dtype for p in params])
@@ -143,9 +168,9 @@ class _MLPScores(torch.autograd.Function):
             gs = g.detach().reshape(-1).to(torch.float32).contiguous()
             partials = torch.empty(grid * info.partial_floats, dtype=torch.float32, device=dev)
             flat = torch.empty(info.n_params, dtype=torch.float32, device=dev)
-            check(lib().ltr_mlp_backward(net, _ptr(x2), n, _ptr(packed), dropout, seed, _ptr(k1), _ptr(k2), _ptr(gs),
+            check(lib().ltr_mlp_backward(info.net, _ptr(x2), n, _ptr(packed), dropout, seed, _ptr(k1), _ptr(k2), _ptr(gs),
                                          _ptr(partials), grid, _stream()), "ltr_mlp_backward")
-            check(lib().ltr_mlp_reduce_grads(net, _ptr(partials), grid, _ptr(flat), _stream()), "ltr_mlp_reduce_grads")
+            reduce_grads(info, partials, grid, flat)
         grads, off = [], 0
         for shape, dt in zip(info.shapes, dtypes):
             cnt = 1
@@ -191,8 +216,8 @@ class FusedRanker:
         if loss not in self.LOSSES:
             raise KeyError(f"fused loss must be one of {sorted(self.LOSSES)}, got {loss!r}")
         self.module = module
-        self.net = module._ltr_net
-        self.info = NetInfo.get(self.net)
+        self.info = NetInfo.get(module._ltr_net)
+        self.net = self.info.net           # the compiled network id the kernels run
         self.loss = loss
         self.loss_kind = self.LOSSES[loss]
         self.alpha, self.eps, self.pad = float(alpha), float(eps), float(padded_value_indicator)
@@ -309,10 +334,10 @@ class FusedRanker:
         with torch.cuda.device(self.device):
             x2 = _docs(X, info)
             yy = y.detach().reshape(B, S).to(torch.float32).contiguous()
-            k1, k2 = _mask(keep1, B * S, info.H1), _mask(keep2, B * S, info.H2)
+            k1, k2 = _mask(keep1, B * S, info.H1, info.cH1), _mask(keep2, B * S, info.H2, info.cH2)
             if self._slate is None or self._slate.numel() < B:
                 self._slate = torch.empty(B, dtype=torch.float32, device=self.device)
-            pack_params(self.net, self.params, out=self.packed)
+            pack_params(self.info.handle, self.params, out=self.packed)
             h = lib()
             if not one_launch:
                 out = self._step_three_launches(h, x2, yy, B, S, dropout, int(seed) & _MASK64, k1, k2, scale, lambda_mean,
@@ -336,8 +361,7 @@ class FusedRanker:
                                        self.grid, _stream()), "ltr_fused_step")
             if self.kernel_events is not None:
                 self.kernel_events[1].record()
-            check(h.ltr_mlp_reduce_grads(self.net, _ptr(self.partials), self.grid, _ptr(self.flat_grad), _stream()),
-                  "ltr_mlp_reduce_grads")
+            reduce_grads(self.info, self.partials, self.grid, self.flat_grad)
             check(h.ltr_reduce_sum_f32(_ptr(self._slate), B, scale, self.flat.data_ptr() + 4 * self.info.n_params,
                                        _stream()), "ltr_reduce_sum_f32")
             if lambda_mean:
@@ -381,8 +405,7 @@ class FusedRanker:
                                        _ptr(self.partials), self.grid, _stream()), "ltr_mlp_backward_saved")
         if self.kernel_events is not None:
             self.kernel_events[1].record()
-        check(h.ltr_mlp_reduce_grads(self.net, _ptr(self.partials), self.grid, _ptr(self.flat_grad), _stream()),
-              "ltr_mlp_reduce_grads")
+        reduce_grads(self.info, self.partials, self.grid, self.flat_grad)
         check(h.ltr_reduce_sum_f32(_ptr(self._slate), B, scale, self.flat.data_ptr() + 4 * self.info.n_params,
                                    _stream()), "ltr_reduce_sum_f32")
         if lambda_mean:

@@ -87,8 +87,10 @@ def test_scorer_modules_construct_on_cpu():
         assert {k: tuple(v.shape) for k, v in t.state_dict().items()} == {
             "l1.weight": (64, F), "l1.bias": (64,), "l2.weight": (32, 64), "l2.bias": (32,), "l3.weight": (1, 32), "l3.bias": (1,)}
         assert isinstance(d.dropout, torch.nn.Dropout) and d.dropout.p == 0.5
+    d = DoubleLayerNet(100)                       # any input size up to 136 runs zero-padded on a compiled geometry
+    assert tuple(d.fc2.weight.shape) == (100, 100) and tuple(TripleLayerNet(46).l1.weight.shape) == (64, 46)
     with pytest.raises(NotImplementedError):
-        DoubleLayerNet(100)
+        DoubleLayerNet(220)                       # a 128-document tile of more than 136 features does not fit LDS
     from ltr_mi355x import LtrDeviceError
     with pytest.raises(LtrDeviceError):
         TripleLayerNet(136)(torch.zeros(2, 4, 136), None, None)

@@ -303,7 +303,49 @@ def test_64_feature_nets(kind, S, dev):
     approxNDCGLoss(scores.squeeze(-1), y.to(dev)).backward()
     assert_grads(_grads(net), fused, 1e-5)
     with pytest.raises(NotImplementedError):
-        _make(kind, dev, 1, F=100)
+        _make(kind, dev, 1, F=220)
+
+
+@pytest.mark.parametrize("kind,F", [("double", 100), ("double", 46), ("double", 5), ("triple", 100), ("triple", 46), ("triple", 72)])
+def test_other_input_sizes_run_zero_padded_on_a_compiled_geometry(kind, F, dev):
+    """DoubleLayerNet(input_size) / TripleLayerNet(N_features) accept any width (doubleLayer.py:55-60, tripleLayer.py:6-10):
+    widths other than the compiled 136 / 64 run zero-padded (ltr_mlp_pack_sub / ltr_mlp_reduce_grads_sub): module path
+    (eval + train mode under exported masks) and the fused pass against the fp64 oracle, gradients in the logical shapes."""
+    from losses.approxNDCG import approxNDCGLoss
+    from ltr_mi355x import scorer
+    from ltr_mi355x.scorer import FusedRanker
+    net, sd = _make(kind, dev, 31 + F, F=F)
+    B, S = 7, 64
+    gen = torch.Generator().manual_seed(F)
+    x = torch.randn(B, S, F, generator=gen)
+    y = torch.randint(0, 5, (B, S), generator=gen).float()
+    for k, v in net.state_dict().items():
+        assert tuple(v.shape) == tuple(sd[k].shape)
+    net.eval()
+    rl, rg, rs = _oracle_step(kind, sd, x, y, "approxNDCG")
+    _, rg32, _ = _oracle_step(kind, sd, x, y, "approxNDCG", dtype=torch.float32)
+    scores = net(x.to(dev), None, None)
+    assert scores.shape == (B, S, 1)
+    assert relerr(scores.detach().cpu().numpy().squeeze(-1), rs) < TOL
+    loss = approxNDCGLoss(scores.squeeze(-1), y.to(dev))
+    loss.backward()
+    assert relerr(loss.detach().cpu().numpy(), rl) < TOL
+    assert_grads(_grads(net), rg, ref32=rg32)
+    net.zero_grad()
+    ranker = FusedRanker(net, loss="approxNDCG")
+    if kind == "double":
+        net.train()
+        seed = 0xABCDEF0123456789
+        k1 = scorer.dropout_keep_mask(seed, 0, B * S, F, dev).cpu().float().view(B, S, F)
+        k2 = scorer.dropout_keep_mask(seed, 1, B * S, F, dev).cpu().float().view(B, S, F)
+        rl, rg, _ = _oracle_step(kind, sd, x, y, "approxNDCG", k1, k2)
+        _, rg32, _ = _oracle_step(kind, sd, x, y, "approxNDCG", k1, k2, dtype=torch.float32)
+        out = ranker.step(x.to(dev), y.to(dev), seed=seed)
+    else:
+        out = ranker.step(x.to(dev), y.to(dev))
+    assert relerr(out.cpu().numpy(), rl) < TOL
+    assert all(tuple(p.grad.shape) == tuple(p.shape) for p in net.parameters())
+    assert_grads(_grads(net), rg, ref32=rg32)
 
 
 def test_fused_edge_cases(dev):

@@ -17,8 +17,6 @@ def dev():
     assert torch.cuda.is_available()
     import ltr_mi355x
     ltr_mi355x.lib()
-    if "bf16x3" in ltr_mi355x.library_path():
-        pytest.skip("the bench-only two-layer net is instantiated in the exact-fp32 library only (ltr_pipeline_bf16x3_net.h: TWO = false)")
     return torch.device("cuda:0")
 
 
