@@ -194,6 +194,11 @@ int ltr_mlp_forward(int net, const float *X, int64_t n_docs, const float *packed
  * kernels derive from (seed, document index, feature index): the counter-based replacement for the torch
  * CPU generator stream behind nn.Dropout (doubleLayer.py:60), which cannot be reproduced on the device. */
 int ltr_dropout_keep_mask(uint64_t seed, int layer, int64_t n_docs, int H, uint8_t *out, void *stream);
+/* Dropout probabilities other than the reference's 0.5 (a caller that sets `net.dropout.p`): every `dropout` argument below is
+ * 0 (off), 1 (on, p = 0.5) or `1 | (bits of the float p with its lowest bit cleared)` (on, that p; kept units scaled by
+ * 1 / (1 - p)).  p = 0.5 draws one hash bit per hidden unit, any other p 16 bits (unit dropped when they are < round(p * 65536)).
+ * ltr_dropout_keep_mask_p exports the stream for such a p. */
+int ltr_dropout_keep_mask_p(uint64_t seed, int layer, int64_t n_docs, int H, float p, uint8_t *out, void *stream);
 
 /* Scorer backward given dL/dscores[n_docs]: recomputes the forward from X (same seed/masks) and leaves one
  * gradient partial per workgroup in `partials` (grid * partial_floats floats); ltr_mlp_reduce_grads then sums

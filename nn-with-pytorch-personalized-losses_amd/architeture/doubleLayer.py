@@ -30,11 +30,9 @@ class DoubleLayerNet(nn.Module):
         return [self.fc1.weight, self.fc1.bias, self.fc2.weight, self.fc2.bias, self.fc3.weight, self.fc3.bias]
 
     def forward(self, x, c1, c2, keep1=None, keep2=None):
-        train = self.training and self.dropout.p > 0
-        if train and self.dropout.p != 0.5:
-            raise NotImplementedError("the fused dropout is compiled for p = 0.5 (doubleLayer.py:60)")
+        train = self.training and self.dropout.p > 0       # (p is 0.5 in the reference, doubleLayer.py:60; any p in [0, 1) runs)
         self._ltr_calls += 1
-        return _scorer.mlp_scores(self._ltr_net, self._ltr_params(), x, dropout=train,
+        return _scorer.mlp_scores(self._ltr_net, self._ltr_params(), x, dropout=_scorer.drop_code(train, self.dropout.p),
                                   seed=_scorer.next_seed(self._ltr_calls), keep1=keep1, keep2=keep2)
 
     def predict(self, x, c1, c2):

@@ -25,6 +25,7 @@
 #include "ltr_slate_losses.h"
 #include <math.h>
 #include <stdlib.h>
+#include <string.h>
 
 
 // LTR_F16X2 = 1 builds the f16 x 2 split variant (libltr_mi355x_f16x2.so, same C ABI): fc1 / fc2 / dh1 -- the GEMMs whose
@@ -145,7 +146,9 @@ struct PipeArgs {
     const uint8_t *keep1;    // optional explicit dropout keep masks [n_docs][H1] / [n_docs][H2]
     const uint8_t *keep2;
     unsigned long long seed;
-    int dropout;             // 1: training-mode dropout p = 0.5 on ACT_RELU_DROP layers
+    int dropout;             // 1: training-mode dropout on ACT_RELU_DROP layers
+    unsigned drop_thr16;     // 0: p = 0.5, one hash BIT per unit (doubleLayer.py:60); else drop a unit when its 16 hash bits < thr
+    float drop_scale;        // 1 / (1 - p): what a kept unit is multiplied by
     int loss_kind;           // 0 approxNDCG, 1 ListNet, 2 LambdaLoss
     LambdaParams lp;         // loss_kind 2
     float *slate_count;      // loss_kind 2: kept pairs per slate (may be NULL)
@@ -413,6 +416,10 @@ __device__ __forceinline__ void activate(f32x4 (&h)[NMAX], int q, const PipeArgs
                 if (in_range && n0 < H) bytes = *reinterpret_cast<const unsigned *>(keep + doc * H + n0);
                 kb = ((bytes & 0xFFu) ? 1u : 0u) | ((bytes & 0xFF00u) ? 2u : 0u) | ((bytes & 0xFF0000u) ? 4u : 0u) |
                      ((bytes & 0xFF000000u) ? 8u : 0u);
+            } else if (a.drop_thr16) {      // any p: 16 hash bits per unit (stream layer + 2, word = unit pair)
+                const unsigned w0 = keep_word(a.seed, layer + 2, doc, 8 * To + 2 * q), w1 = keep_word(a.seed, layer + 2, doc, 8 * To + 2 * q + 1);
+                kb = ((w0 & 0xffffu) >= a.drop_thr16 ? 1u : 0u) | ((w0 >> 16) >= a.drop_thr16 ? 2u : 0u) |
+                     ((w1 & 0xffffu) >= a.drop_thr16 ? 4u : 0u) | ((w1 >> 16) >= a.drop_thr16 ? 8u : 0u);
             } else {
                 const unsigned wbits = keep_word(a.seed, layer, doc, To >> 1);
                 kb = (wbits >> (16 * (To & 1) + 4 * q)) & 0xFu;
@@ -425,7 +432,7 @@ __device__ __forceinline__ void activate(f32x4 (&h)[NMAX], int q, const PipeArgs
                 v = fmaxf(v, 0.f);
                 if (drop) {
                     const int m = ((int)(kb << (31 - r))) >> 31;                  // 0 or ~0
-                    v = __builtin_bit_cast(float, __builtin_bit_cast(int, v + v) & m);
+                    v = __builtin_bit_cast(float, __builtin_bit_cast(int, v * a.drop_scale) & m);   // p = 0.5: v * 2 == v + v
                 }
             } else if (ACT == ACT_SIGMOID) {
                 v = __frcp_rn(1.f + __expf(-v));
@@ -707,7 +714,7 @@ __device__ __forceinline__ int grow_exp(int ex, float m) {
     int e = __builtin_amdgcn_frexp_expf(m);
     e = m > 0.f ? e : -100;
     e = e < -100 ? -100 : e;
-    return e > ex ? e : ex;
+    return __builtin_amdgcn_readfirstlane(e > ex ? e : ex);      // wave-uniform by construction: keep it in an SGPR
 }
 #endif
 
@@ -879,7 +886,7 @@ __global__ void __launch_bounds__(kThreads, 2) slate_pipeline_kernel(const PipeA
         __syncthreads();                                   // w3s is complete
         float m = 0.f;
         for (int j = lane; j < N::NT2 * 16; j += 64) m = fmaxf(m, fabsf(w3s[j]));
-        w3max = wave_allmax(m);
+        w3max = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, wave_allmax(m))));
     } else
 #endif
     if (XDMA) {   // pad columns of the X tile (ones feature at column F, zeros up to LD): constant, written once
@@ -1184,7 +1191,7 @@ __global__ void __launch_bounds__(kThreads, 2) slate_pipeline_kernel(const PipeA
         // documents past the end of the batch must not contribute to any gradient
         const float ds0 = gdoc < a.n_docs ? dsc[my_row] : 0.f;
         db3 += wave_allsum((q == 0) ? ds0 : 0.f);
-        const float slope = a.dropout ? 2.f : 1.f;                       // d relu-dropout / dz where it is live
+        const float slope = a.dropout ? a.drop_scale : 1.f;              // d relu-dropout / dz where it is live
         const float ds2 = (N::A2 == ACT_RELU_DROP) ? ds0 * slope : ds0;
 #pragma unroll
         for (int To = 0; To < N::NT2; ++To) {
@@ -1225,7 +1232,8 @@ __global__ void __launch_bounds__(kThreads, 2) slate_pipeline_kernel(const PipeA
             exh = grow_exp(exh, hm);
             const float dm = wave_allmax(fmaxf(fabsf(dsc[lane]), fabsf(dsc[lane + 64])));
             exd2 = grow_exp(exd2, dm * slope * w3max);
-            if (exd2 + exh != E2) {                        // the scale grew: bring the accumulators along (exact: a power of two)
+            {   // if the scale grew, bring the accumulators along (a power of two: exact).  Branch-free -- f = 1 almost always --
+                // because a conditional update of 44 live accumulators costs more in spills than the 44 multiplies
                 const float f = ldexpf(1.f, E2 - (exd2 + exh));
 #pragma unroll
                 for (int n = 0; n < N::TW2; ++n) accW2[n] *= f;
@@ -1336,7 +1344,7 @@ __global__ void __launch_bounds__(kThreads, 2) slate_pipeline_kernel(const PipeA
 #pragma unroll
             for (int i = 0; i < kWaves; ++i) dm = fmaxf(dm, exch[16 + i]);
             exd1 = grow_exp(exd1, dm);
-            if (exd1 + exx != E1) {
+            {
                 const float f = ldexpf(1.f, E1 - (exd1 + exx));
 #pragma unroll
                 for (int n = 0; n < N::TW1; ++n) accW1[n] *= f;
@@ -1434,12 +1442,27 @@ __global__ void __launch_bounds__(kThreads, 2) slate_pipeline_kernel(const PipeA
 
 
 // The keep mask the pipeline's counter-based dropout stream produces (tests / reproducibility tooling).
-__global__ void dropout_mask_kernel(unsigned long long seed, int layer, long long n_docs, int H, uint8_t *out) {
+__global__ void dropout_mask_kernel(unsigned long long seed, int layer, long long n_docs, int H, unsigned thr16, uint8_t *out) {
     const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= n_docs * H) return;
     const long long doc = e / H;
     const int n = (int)(e - doc * H);
-    out[e] = (keep_word(seed, layer, doc, n >> 5) >> (n & 31)) & 1u;
+    if (thr16) out[e] = ((keep_word(seed, layer + 2, doc, n >> 1) >> (16 * (n & 1))) & 0xffffu) >= thr16 ? 1 : 0;
+    else out[e] = (keep_word(seed, layer, doc, n >> 5) >> (n & 31)) & 1u;
+}
+
+// `dropout` argument of the launchers: 0 = off; bit 0 set = on with p = the float whose bits are (dropout & ~1) -- 0 there (the
+// plain value 1) means the reference's p = 0.5.  p = 0.5 keeps the one-bit-per-unit stream, any other p draws 16 bits per unit.
+static inline void decode_dropout(int dropout, int &on, unsigned &thr16, float &scale) {
+    on = dropout & 1;
+    unsigned bits = (unsigned)dropout & ~1u;
+    float p = 0.5f;
+    if (bits) memcpy(&p, &bits, sizeof p);
+    if (!(p > 0.f)) on = 0;
+    if (!(p < 1.f)) p = 0.5f;           // rejected by fill_common
+    thr16 = p == 0.5f ? 0u : (unsigned)(p * 65536.f + 0.5f);
+    if (thr16 > 65535u) thr16 = 65535u;
+    scale = 1.f / (1.f - p);
 }
 
 // Pack nn.Linear parameters into lane-ordered MFMA A-fragments (once per optimizer step; 37k params).
@@ -1627,13 +1650,26 @@ int ltr_net_info(int net, int32_t *info) {
     return LTR_OK;
 }
 
+int ltr_dropout_keep_mask_p(uint64_t seed, int layer, int64_t n_docs, int H, float p, uint8_t *out, void *stream) {
+    if (!out) return LTR_ERR_NULL;
+    if (n_docs < 0 || H < 1 || H > 4096 || layer < 0 || layer > 1) return LTR_ERR_SHAPE;
+    if (!(p > 0.f && p < 1.f)) return LTR_ERR_PARAM;
+    const long long n = n_docs * H;
+    if (n == 0) return LTR_OK;
+    unsigned thr16 = p == 0.5f ? 0u : (unsigned)(p * 65536.f + 0.5f);
+    if (thr16 > 65535u) thr16 = 65535u;
+    hipLaunchKernelGGL(dropout_mask_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, seed,
+                       layer, (long long)n_docs, H, thr16, out);
+    return status();
+}
+
 int ltr_dropout_keep_mask(uint64_t seed, int layer, int64_t n_docs, int H, uint8_t *out, void *stream) {
     if (!out) return LTR_ERR_NULL;
     if (n_docs < 0 || H < 1 || H > 4096 || layer < 0 || layer > 1) return LTR_ERR_SHAPE;
     const long long n = n_docs * H;
     if (n == 0) return LTR_OK;
     hipLaunchKernelGGL(dropout_mask_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, seed,
-                       layer, (long long)n_docs, H, out);
+                       layer, (long long)n_docs, H, 0u, out);
     return status();
 }
 
@@ -1679,7 +1715,13 @@ static int fill_common(PipeArgs &a, int net, const float *X, int64_t n_docs, con
     a.X = X;
     a.n_docs = n_docs;
     a.packed = packed;
-    a.dropout = dropout ? 1 : 0;
+    {
+        unsigned bits = (unsigned)dropout & ~1u;
+        float p = 0.5f;
+        if (bits) memcpy(&p, &bits, sizeof p);
+        if ((dropout & 1) && !(p >= 0.f && p < 1.f)) return LTR_ERR_PARAM;
+    }
+    decode_dropout(dropout, a.dropout, a.drop_thr16, a.drop_scale);
     a.seed = seed;
     a.keep1 = keep1;
     a.keep2 = keep2;

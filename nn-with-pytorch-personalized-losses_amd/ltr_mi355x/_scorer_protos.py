@@ -8,6 +8,7 @@ PROTOTYPES = {
     "ltr_mlp_pack_sub": (c_int, [c_int, c_int, c_int, c_int, P, P, P, P, P, P, P, P]),
     "ltr_mlp_reduce_grads_sub": (c_int, [c_int, c_int, c_int, c_int, P, c_int, P, P]),
     "ltr_dropout_keep_mask": (c_int, [c_uint64, c_int, c_int64, c_int, P, P]),
+    "ltr_dropout_keep_mask_p": (c_int, [c_uint64, c_int, c_int64, c_int, c_float, P, P]),
     "ltr_mlp_forward": (c_int, [c_int, P, c_int64, P, c_int, c_uint64, P, P, P, c_int, P]),
     "ltr_mlp_backward": (c_int, [c_int, P, c_int64, P, c_int, c_uint64, P, P, P, P, c_int, P]),
     "ltr_mlp_reduce_grads": (c_int, [c_int, P, c_int, P, P]),

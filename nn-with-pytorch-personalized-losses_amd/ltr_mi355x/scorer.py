@@ -184,10 +184,34 @@ class _MLPScores(torch.autograd.Function):
 def mlp_scores(net, params, x, dropout=False, seed=0, keep1=None, keep2=None):
     """scores[..., 1] = net(x) on the device.  x: [..., F] fp32 device tensor.  No gradient w.r.t. x."""
     require_device(x, *params)
-    return _MLPScores.apply(x, net, bool(dropout), int(seed), keep1, keep2, *params)
+    return _MLPScores.apply(x, net, int(dropout), int(seed), keep1, keep2, *params)
 
 
-def dropout_keep_mask(seed, layer, n_docs, H, device):
+def drop_code(train, p=0.5):
+    """The `dropout` argument of the C launchers (include/ltr_mi355x.h): 0 = off, 1 = on with the reference's p = 0.5
+    (doubleLayer.py:60), otherwise 1 | (the bits of float32(p) with the lowest one cleared)."""
+    p = float(p)
+    if not train or p <= 0.0:
+        return 0
+    if not p < 1.0:
+        raise ValueError(f"dropout probability has to be between 0 and 1, but got {p}")
+    if p == 0.5:
+        return 1
+    import struct
+    return 1 | (struct.unpack("<I", struct.pack("<f", p))[0] & ~1)
+
+
+def dropout_keep_mask(seed, layer, n_docs, H, device, p=0.5):
+    if p != 0.5:
+        out = torch.empty((n_docs, H), dtype=torch.uint8, device=device)
+        with torch.cuda.device(device):
+            check(lib().ltr_dropout_keep_mask_p(int(seed) & _MASK64, layer, n_docs, H, float(p), _ptr(out), _stream()),
+                  "ltr_dropout_keep_mask_p")
+        return out
+    return _dropout_keep_mask_half(seed, layer, n_docs, H, device)
+
+
+def _dropout_keep_mask_half(seed, layer, n_docs, H, device):
     out = torch.empty((n_docs, H), dtype=torch.uint8, device=device)
     with torch.cuda.device(device):
         check(lib().ltr_dropout_keep_mask(int(seed) & _MASK64, layer, n_docs, H, _ptr(out), _stream()),
@@ -327,7 +351,7 @@ class FusedRanker:
             self._norm.fill_(float(B))
         count = None
         train = self.module.training if train is None else train
-        dropout = bool(train and self.module._ltr_dropout)
+        dropout = drop_code(bool(train and self.module._ltr_dropout), getattr(getattr(self.module, "dropout", None), "p", 0.5))
         if seed is None:
             seed = next_seed(self._calls) ^ ((self.seed_salt * 0xA24BAED4963EE407) & _MASK64)
         self._calls += 1

@@ -331,16 +331,17 @@ def ordinal_closed_form(y_pred, y_true, n, pad=-1):
 
 
 # --------------------------------------------------------------------------------------- scorers
-def double_layer_forward(x, p, keep1=None, keep2=None):
+def double_layer_forward(x, p, keep1=None, keep2=None, drop_p=0.5):
     """DoubleLayerNet (architeture/doubleLayer.py:54-73): fc3(drop(relu(fc2(drop(relu(fc1 x)))))).
-    keep1/keep2: optional {0,1} keep masks [.., hidden]; dropout p=0.5 scales kept units by 2.
-    None -> predict()/eval() path (no dropout).  `p` maps state_dict keys to tensors."""
+    keep1/keep2: optional {0,1} keep masks [.., hidden]; dropout scales kept units by 1 / (1 - drop_p) (the reference's
+    nn.Dropout(p=0.5), :60: by 2).  None -> predict()/eval() path (no dropout).  `p` maps state_dict keys to tensors."""
+    scale = 1.0 / (1.0 - drop_p)
     h = torch.relu(x @ p["fc1.weight"].T + p["fc1.bias"])
     if keep1 is not None:
-        h = h * keep1 * 2.0
+        h = h * keep1 * scale
     h = torch.relu(h @ p["fc2.weight"].T + p["fc2.bias"])
     if keep2 is not None:
-        h = h * keep2 * 2.0
+        h = h * keep2 * scale
     return h @ p["fc3.weight"].T + p["fc3.bias"]
 
 

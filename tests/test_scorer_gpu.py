@@ -120,14 +120,14 @@ def test_double_golden(dev):
 LAMBDA_KW = dict(weighing_scheme="ndcgLoss2PP_scheme", k=None, sigma=1.0, mu=10.0, reduction="sum", reduction_log="binary")
 
 
-def _oracle_step(kind, sd, x, y, loss, k1=None, k2=None, dtype=torch.float64, lambda_kw=None):
+def _oracle_step(kind, sd, x, y, loss, k1=None, k2=None, dtype=torch.float64, lambda_kw=None, drop_p=0.5):
     """CPU oracle (fp64 by default): loss and parameter gradients by autograd over the restatement."""
     p = {k: v.to(dtype).clone().requires_grad_(True) for k, v in sd.items()}
     xd = x.to(dtype)
     if kind == "triple":
         s = O.triple_layer_forward(xd, p)
     else:
-        s = O.double_layer_forward(xd, p, None if k1 is None else k1.to(dtype), None if k2 is None else k2.to(dtype))
+        s = O.double_layer_forward(xd, p, None if k1 is None else k1.to(dtype), None if k2 is None else k2.to(dtype), drop_p)
     s = s.squeeze(-1)
     if loss == "approxNDCG":
         l = O.approx_ndcg(s, y.to(dtype))
@@ -477,3 +477,35 @@ def test_fused_full_size_properties(dev):
     ln = ranker.step(X[:n], y[:n])
     assert relerr(ln.cpu().numpy(), rl) < TOL
     assert_grads(_grads(net), rg)
+
+
+@pytest.mark.parametrize("p,S", [(0.1, 128), (0.3, 64), (0.75, 100)])
+def test_other_dropout_probabilities(p, S, dev):
+    """nn.Dropout(p) with p != 0.5 on DoubleLayerNet (`net.dropout.p = p`; the reference hard-codes 0.5, doubleLayer.py:60): the
+    16-bit-per-unit stream, exported by ltr_dropout_keep_mask_p, against the fp64 oracle under the same masks -- one-launch fused
+    pass (S in {64, 128}) and the forward / loss / backward launches (S = 100)."""
+    from ltr_mi355x import scorer
+    from ltr_mi355x.scorer import FusedRanker
+    net, sd = _make("double", dev, 41)
+    net.dropout.p = p
+    net.train()
+    B = 6
+    gen = torch.Generator().manual_seed(int(1000 * p) + S)
+    x = torch.randn(B, S, 136, generator=gen)
+    y = torch.randint(0, 5, (B, S), generator=gen).float()
+    seed = 0x0F1E2D3C4B5A6978
+    k1 = scorer.dropout_keep_mask(seed, 0, B * S, 136, dev, p=p).cpu().float().view(B, S, 136)
+    k2 = scorer.dropout_keep_mask(seed, 1, B * S, 136, dev, p=p).cpu().float().view(B, S, 136)
+    assert abs(float(k1.mean()) - (1 - p)) < 0.02 and abs(float(k2.mean()) - (1 - p)) < 0.02
+    assert not torch.equal(k1, k2)
+    rl, rg, _ = _oracle_step("double", sd, x, y, "approxNDCG", k1, k2, drop_p=p)
+    _, rg32, _ = _oracle_step("double", sd, x, y, "approxNDCG", k1, k2, dtype=torch.float32, drop_p=p)
+    out = FusedRanker(net, loss="approxNDCG").step(x.to(dev), y.to(dev), seed=seed)
+    assert relerr(out.cpu().numpy(), rl) < TOL
+    assert_grads(_grads(net), rg, ref32=rg32)
+    # module path: train-mode forwards differ from eval, and from each other (fresh seeds)
+    a, b = net(x.to(dev), None, None), net(x.to(dev), None, None)
+    assert not torch.equal(a, b)
+    net.dropout.p = 1.5
+    with pytest.raises(ValueError):
+        net(x.to(dev), None, None)
