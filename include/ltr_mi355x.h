@@ -170,6 +170,9 @@ enum { LTR_LOSS_APPROXNDCG = 0, LTR_LOSS_LISTNET = 1 };
 
 /* info[0..7] = F, H1, H2, n_params, packed_floats, partial_floats (per workgroup), docs_per_tile, lds_bytes */
 int ltr_net_info(int net, int32_t *info);
+/* Number of persistent workgroups the fused step of `net` wants on a device with n_cus compute units (one per CU; two for
+ * kernels that run two 256-thread workgroups per CU).  `partials` must hold that many * partial_floats floats. */
+int ltr_fused_grid(int net, int n_cus);
 
 int ltr_mlp_pack(int net, const float *W1, const float *b1, const float *W2, const float *b2, const float *w3,
                  const float *b3, float *packed, void *stream);
@@ -197,7 +200,9 @@ int ltr_dropout_keep_mask(uint64_t seed, int layer, int64_t n_docs, int H, uint8
 /* Dropout probabilities other than the reference's 0.5 (a caller that sets `net.dropout.p`): every `dropout` argument below is
  * 0 (off), 1 (on, p = 0.5) or `1 | (bits of the float p with its lowest bit cleared)` (on, that p; kept units scaled by
  * 1 / (1 - p)).  p = 0.5 draws one hash bit per hidden unit, any other p 16 bits (unit dropped when they are < round(p * 65536)).
- * ltr_dropout_keep_mask_p exports the stream for such a p. */
+ * Only the forward kernels carry the 16-bit stream: with such a p use ltr_mlp_forward / ltr_mlp_forward_save and
+ * ltr_mlp_backward_saved (the saved activations make the backward independent of the stream); ltr_mlp_backward and the fused
+ * steps return LTR_ERR_PARAM for it unless explicit keep masks are passed.  ltr_dropout_keep_mask_p exports the stream. */
 int ltr_dropout_keep_mask_p(uint64_t seed, int layer, int64_t n_docs, int H, float p, uint8_t *out, void *stream);
 
 /* Scorer backward given dL/dscores[n_docs]: recomputes the forward from X (same seed/masks) and leaves one

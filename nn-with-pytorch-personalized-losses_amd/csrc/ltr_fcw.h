@@ -1,0 +1,332 @@
+// ltr_fcw.h -- the fused slate pipeline of the TWO-LAYER scorer (136 -> 64 -> 1: the DoubleLayerNet variant of
+// architeture/doubleLayer.py:38-51 that BASELINE.json configs[0] / [1] name), re-laid-out for the f16 x 2 arithmetic of the
+// variant library (-DLTR_F16X2=1).  Included by ltr_scorer.hip inside its anonymous namespace.
+//
+// The generic pipeline (slate_pipeline_kernel) gives every wave 16 documents and ALL hidden units: every wave then reads every
+// weight, and dz has to be staged through LDS for the document contraction of dW.  Here the HIDDEN UNITS are partitioned instead
+// ("weights-stationary"): a workgroup is 4 waves, wave w owns hidden units 16w .. 16w+15 for all 128 documents of the tile.
+//   * its W1 fragments (hi / lo f16, 5 k-steps: 40 VGPRs) are loaded ONCE per kernel and stay in registers;
+//   * fc1 runs NON-transposed, z1[doc][n] = sum_f x[doc][f] W1[n][f]: A = rows of the X image pair in LDS (ds_read_b128, conflict
+//     free), B = the resident fragments; the accumulator tile (row = document, col = hidden unit) of two document tiles IS the A
+//     operand of the weight gradient dW1[n][f] = sum_doc dz1[doc][n] x[doc][f] (k = documents, same k-slot order as the
+//     transposing LDS read that supplies x) -- no staging, no barrier between the backward through fc3 and dW1;
+//   * the scores need one exchange (each wave holds a 16-unit partial of w3 . h1): 2 KB through LDS.
+// 256 threads and 80 KB of LDS per workgroup -> TWO workgroups per CU: the listwise loss of one slate (barrier- and latency-bound,
+// matrix pipe idle) runs under the other workgroup's load / convert / MFMA phases.
+#pragma once
+
+#ifdef LTR_STAMPS
+#define FCW_STAMP(k)                                                                                          \
+    if (a.stamps && lane == 0 && (st - (int)blockIdx.x) / (int)gridDim.x == a.stamp_tile)                      \
+        a.stamps[((size_t)blockIdx.x * 8 + w) * 16 + (k)] = __builtin_readcyclecounter();
+#else
+#define FCW_STAMP(k)
+#endif
+
+constexpr int kFcwWaves = 4;
+constexpr int kFcwThreads = kFcwWaves * 64;
+
+template <class N>
+constexpr size_t fcw_lds() {
+    // X image pair [128][LD] halfs x 2 (+ 32 B so that the last k-step's over-read of the last row stays inside finite f16s),
+    // 8 loss arrays [128], score partials [4][128], slate-group scratch [256 + 4*32], 16 exchange floats
+    return (size_t)2 * kTileDocs * N::LD * 2 + 32 + sizeof(float) * (8 * kTileDocs + kFcwWaves * kTileDocs + kFcwThreads + 4 * 32 + 16);
+}
+
+template <class N, int LOSS>
+__global__ void __launch_bounds__(kFcwThreads, 2) fcw_fused_kernel(const PipeArgs a) {
+    static_assert(N::TWO && N::H1 == 16 * kFcwWaves, "one hidden tile per wave");
+    constexpr int LDH = N::LD;                       // halfs per image row (72 dwords at LD = 144: conflict-free both ways)
+    constexpr int KP = N::KP1;                       // 32-wide k-steps over the features (+ the ones feature)
+    constexpr int XT = N::XT;
+    extern __shared__ __attribute__((aligned(16))) float smem_f[];
+    uint16_t *Xhi = reinterpret_cast<uint16_t *>(smem_f), *Xlo = Xhi + kTileDocs * LDH;
+    float *sc = reinterpret_cast<float *>(Xlo + kTileDocs * LDH + 16);
+    float *yl = sc + kTileDocs, *gn = yl + kTileDocs, *gg = gn + kTileDocs, *dsc = gg + kTileDocs, *uu = dsc + kTileDocs,
+          *mk = uu + kTileDocs, *xt = mk + kTileDocs;
+    float *part = xt + kTileDocs;                    // [4][128] per-wave score partials
+    float *scratch = part + kFcwWaves * kTileDocs;   // [256 + 4*32]
+    float *exch = scratch + kFcwThreads + 4 * 32;    // [16]
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int q = lane >> 4, d = lane & 15;
+    const int n_mine = 16 * w + d;                   // this lane's hidden unit (accumulator column)
+
+    // ---- once per kernel: resident W1 fragments, w3, zero pads of the images, loss scratch
+    h16x8 wh[KP], wl[KP];
+    {
+        const uint4 *src = reinterpret_cast<const uint4 *>(a.packed + N::W1B_OFF) + (size_t)w * KP * 2 * 64 + lane;
+#pragma unroll
+        for (int P = 0; P < KP; ++P) {
+            wh[P] = __builtin_bit_cast(h16x8, src[(2 * P) * 64]);
+            wl[P] = __builtin_bit_cast(h16x8, src[(2 * P + 1) * 64]);
+        }
+    }
+    const float w3n = a.packed[N::W3_OFF + n_mine];
+    const float b3 = a.packed[N::W3_OFF + N::NT2 * 16];
+    const float inv_w1 = a.packed[N::W3_OFF + N::NT2 * 16 + 4];
+    float w3max = 0.f;
+    for (int j = lane; j < N::H2; j += 64) w3max = fmaxf(w3max, fabsf(a.packed[N::W3_OFF + j]));
+    w3max = wave_allmax(w3max);
+    for (int e = tid; e < kTileDocs * (LDH - N::F); e += kFcwThreads) {
+        const int r = e / (LDH - N::F), c = N::F + e % (LDH - N::F);
+        Xhi[r * LDH + c] = 0;
+        Xlo[r * LDH + c] = 0;
+    }
+    if (tid < 16) Xlo[kTileDocs * LDH + tid] = 0;
+    for (int j = tid; j < kFcwThreads + 4 * 32; j += kFcwThreads) scratch[j] = 0.f;
+    f32x4 accW[XT];                                  // dW1 tiles (rows = my 16 hidden units, cols = 16 features each)
+#pragma unroll
+    for (int t = 0; t < XT; ++t) accW[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float dw3 = 0.f, db3 = 0.f;
+    int exx = 1, exd = -100, E = -400;
+
+    constexpr int V4_PER_ROW = N::F / 4, ROWS = kTileDocs / kFcwWaves, V4 = ROWS * V4_PER_ROW;   // this wave converts 32 rows
+    constexpr int NV = (V4 + 63) / 64;
+    for (int st = blockIdx.x; st < a.n_super; st += gridDim.x) {
+        const long long doc_base = (long long)st * kTileDocs;
+        FCW_STAMP(0)
+        // ---- X: this wave's 32 rows HBM -> registers (nothing in LDS is touched yet: the loads fly across the barrier)
+        f32x4 xn[NV];
+        {   // one buffer descriptor per wave and tile, sized to the rows that exist: the hardware bounds check returns zeros for
+            // rows past the end of the batch (no per-element compare, no 64-bit address registers)
+            static_assert(V4 % 64 == 0, "the wave's row block is a whole number of 1 KiB wave loads");
+            const long long row0 = doc_base + ROWS * w;
+            long long rows_here = a.n_docs - row0;
+            rows_here = rows_here < 0 ? 0 : (rows_here > ROWS ? ROWS : rows_here);
+            const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.X + (rows_here ? row0 : 0) * N::F), 0,
+                                                                                 (int)rows_here * N::F * 4, 0x00020000);
+#pragma unroll
+            for (int m = 0; m < NV; ++m)
+                xn[m] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xr, lane * 16 + m * 1024, 0, 2 /* nt */));
+        }
+        float xm = 0.f;
+#pragma unroll
+        for (int m = 0; m < NV; ++m)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) xm = fmaxf(xm, fabsf(xn[m][r]));
+        xm = wave_allmax(xm);
+        FCW_STAMP(1)
+        __syncthreads();                              // A: every wave is done with the previous tile's images, scores, gradients
+        if (lane == 0) exch[w] = xm;
+        if (tid < kTileDocs) {
+            const long long doc = doc_base + tid;
+            const float y = doc < (long long)a.B * a.S ? a.labels[doc] : a.pad;
+            if (LOSS != 1) stage_label(y, a.pad, yl[tid], gn[tid]);
+            else yl[tid] = doc < (long long)a.B * a.S ? y : 0.f;
+        }
+        __syncthreads();                              // B: the four row-block maxima are out
+        FCW_STAMP(2)
+        {
+            float m4 = 1.f;                           // the ones feature
+#pragma unroll
+            for (int i = 0; i < kFcwWaves; ++i) m4 = fmaxf(m4, exch[i]);
+            exx = grow_exp(exx, m4);
+            const float sx = ldexpf(1.f, 14 - exx);
+#pragma unroll
+            for (int m = 0; m < NV; ++m) {
+                const int e = lane + 64 * m;
+                if (e < V4) {
+                    u32x2 hi, lo;
+                    split4(xn[m], sx, hi, lo);
+                    const int off = (ROWS * w + e / V4_PER_ROW) * LDH + 4 * (e % V4_PER_ROW);
+                    *reinterpret_cast<u32x2 *>(Xhi + off) = hi;
+                    *reinterpret_cast<u32x2 *>(Xlo + off) = lo;
+                }
+            }
+            if (lane < ROWS) {
+                Xhi[(ROWS * w + lane) * LDH + N::F] = __builtin_bit_cast(uint16_t, (_Float16)sx);
+                Xlo[(ROWS * w + lane) * LDH + N::F] = 0;
+            }
+        }
+        __syncthreads();                              // C: the image pair is complete
+        FCW_STAMP(3)
+        // ---- fc1: z1[doc][n] for my 16 hidden units, all 8 document tiles; A = image rows, B = resident fragments
+        f32x4 h1[8];
+        {
+            const uint16_t *rh = Xhi + d * LDH + 8 * q, *rl = Xlo + d * LDH + 8 * q;
+            u32x4 fh[2][KP], fl[2][KP];              // A fragments of two document tiles: the reads of T+1 fly under the MFMAs of T
+#pragma unroll
+            for (int P = 0; P < KP; ++P) {
+                fh[0][P] = *reinterpret_cast<const u32x4 *>(rh + 32 * P);
+                fl[0][P] = *reinterpret_cast<const u32x4 *>(rl + 32 * P);
+            }
+#pragma unroll
+            for (int T = 0; T < 8; ++T) {
+                if (T + 1 < 8) {
+#pragma unroll
+                    for (int P = 0; P < KP; ++P) {
+                        fh[(T + 1) & 1][P] = *reinterpret_cast<const u32x4 *>(rh + 16 * (T + 1) * LDH + 32 * P);
+                        fl[(T + 1) & 1][P] = *reinterpret_cast<const u32x4 *>(rl + 16 * (T + 1) * LDH + 32 * P);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int P = 0; P < KP; ++P) {
+                    const h16x8 ahi = __builtin_bit_cast(h16x8, fh[T & 1][P]), alo = __builtin_bit_cast(h16x8, fl[T & 1][P]);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ahi, wh[P], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ahi, wl[P], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(alo, wh[P], acc, 0, 0, 0);
+                    if (LTR_LOLO) acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(alo, wl[P], acc, 0, 0, 0);
+                }
+                h1[T] = acc;
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        FCW_STAMP(4)
+        // ---- activation (+ dropout), score partial w3 . h1 over my 16 units
+        const float un = ldexpf(inv_w1, exx - 14);
+        const bool drop = (N::A1 == ACT_RELU_DROP) && a.dropout;
+        long long left64 = a.n_docs - doc_base;
+        const int docs_left = (int)(left64 > kTileDocs ? kTileDocs : left64);        // documents of this tile that exist (uniform)
+#pragma unroll
+        for (int T = 0; T < 8; ++T)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float v = h1[T][r] * un;
+                if (N::A1 == ACT_RELU_DROP) v = fmaxf(v, 0.f);
+                else if (N::A1 == ACT_SIGMOID) v = __frcp_rn(1.f + __expf(-v));
+                h1[T][r] = v;
+            }
+        if (drop) {      // (uniform) training-mode dropout: its own loop, so that the hash arithmetic does not sit in the common path
+#pragma unroll
+            for (int T = 0; T < 8; ++T)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int dl = 16 * T + 4 * q + r;
+                    const long long doc = doc_base + dl;
+                    bool keep;
+                    if (a.keep1) keep = dl < docs_left && a.keep1[doc * N::H1 + n_mine] != 0;
+                    else keep = (keep_word(a.seed, 0, doc, n_mine >> 5) >> (n_mine & 31)) & 1u;
+                    h1[T][r] = keep ? h1[T][r] * a.drop_scale : 0.f;
+                }
+        }
+        // score partial w3 . h1 over my 16 hidden units: sum over the 16 lanes of a DPP row, for each of my 32 documents
+#pragma unroll
+        for (int T = 0; T < 8; ++T) {
+            f32x4 sv;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) sv[r] = row_sum_to_lane15(h1[T][r] * w3n);
+            if (d == 15) *reinterpret_cast<f32x4 *>(part + w * kTileDocs + 16 * T + 4 * q) = sv;
+        }
+        FCW_STAMP(5)
+        __syncthreads();                              // D: the four partials of every document are out
+        if (tid < kTileDocs) sc[tid] = ((part[tid] + part[kTileDocs + tid]) + (part[2 * kTileDocs + tid] + part[3 * kTileDocs + tid])) + b3;
+        __syncthreads();
+        FCW_STAMP(6)
+        // ---- listwise loss on the LDS-resident scores -> dsc (2 threads per document row)
+        {
+            const int group = 2 * a.S;
+            const int gid = tid / group;
+            const SlateGroup g = make_group(a.S, group, scratch + gid * (group + 32), tid);
+            const int so = gid * a.S;
+            const long long slate = (long long)st * (kTileDocs / a.S) + gid;
+            float loss;
+            if (LOSS == 0) {
+                auto st_ds = [&](int i, float v) { dsc[so + i] = v; };
+                ApproxScratch xs;
+                xs.um = xt + so;
+                auto stamp_fn = [&](int k) { FCW_STAMP(k) };
+                if (a.S == 128)
+                    loss = approx_ndcg_slate<64>(g, sc + so, yl + so, gn + so, gg + so, uu + so, mk + so, a.alpha, a.eps, a.gscale, true, st_ds,
+                                                 stamp_fn, xs);
+                else if (a.S == 64)
+                    loss = approx_ndcg_slate<32>(g, sc + so, yl + so, gn + so, gg + so, uu + so, mk + so, a.alpha, a.eps, a.gscale, true, st_ds,
+                                                 NoStamp(), xs);
+                else
+                    loss = approx_ndcg_slate<16>(g, sc + so, yl + so, gn + so, gg + so, uu + so, mk + so, a.alpha, a.eps, a.gscale, true, st_ds,
+                                                 NoStamp(), xs);
+            } else if (LOSS == 1) {
+                loss = listnet_slate(g, yl + so, sc + so, a.apply_sigmoid != 0, a.gscale, true, [&](int i, float v) { dsc[so + i] = v; });
+            } else {
+                LambdaLds L;
+                L.sc = sc + so; L.yl = yl + so; L.gn = gn + so; L.w1 = gg + so; L.invd = uu + so; L.delta = mk + so;
+                L.rk = reinterpret_cast<int *>(xt + so);
+                float count;
+                loss = lambda_slate<-1>(g, L, a.lp, a.gscale, true, &count, [&](int i, float v) { dsc[so + i] = v; });
+                if (g.t == 0 && slate < a.B && a.slate_count) a.slate_count[slate] = count;
+            }
+            if (g.t == 0 && slate < a.B) a.slate_loss[slate] = loss;
+        }
+        __syncthreads();                              // E: d loss / d score of the whole tile
+        FCW_STAMP(7)
+        // ---- backward through fc3: dw3[n] += sum_doc ds h1, dz1 = ds w3 act'(h1); documents past the batch carry no gradient
+        const float slope = drop ? a.drop_scale : 1.f;
+        float dmx = fmaxf(fabsf(dsc[lane]), fabsf(dsc[lane + 64]));
+        dmx = wave_allmax(dmx);
+        if (w == 0) db3 += wave_allsum((lane < docs_left ? dsc[lane] : 0.f) + (lane + 64 < docs_left ? dsc[lane + 64] : 0.f));
+        exd = grow_exp(exd, dmx * slope * w3max);
+        if (exd + exx != E) {
+            const float f = ldexpf(1.f, E - (exd + exx));
+#pragma unroll
+            for (int t = 0; t < XT; ++t) accW[t] *= f;
+            E = exd + exx;
+        }
+        const float sd = ldexpf(1.f, 14 - exd);
+#pragma unroll
+        for (int T = 0; T < 8; ++T) {
+            const f32x4 ds4 = *reinterpret_cast<const f32x4 *>(dsc + 16 * T + 4 * q);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float ds = 16 * T + 4 * q + r < docs_left ? ds4[r] : 0.f;
+                dw3 = fmaf(ds, h1[T][r], dw3);
+                h1[T][r] = apply_act_grad<N::A1>(ds * slope * w3n, h1[T][r]);        // now dz1
+            }
+        }
+        FCW_STAMP(8)
+        // ---- dW1[n][f] += sum_doc dz1[doc][n] x[doc][f]: A = two accumulator tiles of dz1 (split in registers), B = x k-major
+        {
+            const int lb = (4 * q + (d >> 2)) * LDH + 4 * (d & 3);
+#pragma unroll
+            for (int Kp = 0; Kp < 4; ++Kp) {
+                h16x8 ahi, alo;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float v = h1[2 * Kp + (j >> 2)][j & 3] * sd;
+                    const _Float16 h = (_Float16)v;
+                    ahi[j] = h;
+                    alo[j] = (_Float16)(v - (float)h);
+                }
+#pragma unroll
+                for (int Ti = 0; Ti < XT; ++Ti) {
+                    const h16x8 bh = tr_frag_h<LDH>(Xhi + lb, 32 * Kp, Ti), bl = tr_frag_h<LDH>(Xlo + lb, 32 * Kp, Ti);
+                    accW[Ti] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ahi, bh, accW[Ti], 0, 0, 0);
+                    accW[Ti] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ahi, bl, accW[Ti], 0, 0, 0);
+                    accW[Ti] = __builtin_amdgcn_mfma_f32_16x16x32_f16(alo, bh, accW[Ti], 0, 0, 0);
+                    if (LTR_LOLO) accW[Ti] = __builtin_amdgcn_mfma_f32_16x16x32_f16(alo, bl, accW[Ti], 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        FCW_STAMP(9)
+    }
+    // ---- per-workgroup partial gradients -> workspace (the layout reduce_grads_kernel<N> sums)
+    float *out = a.partials + (size_t)blockIdx.x * N::PART;
+    const float us = ldexpf(1.f, E - 28);
+#pragma unroll
+    for (int Ti = 0; Ti < XT; ++Ti)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) out[N::P_W1 + (16 * w + 4 * q + r) * (XT * 16) + 16 * Ti + d] = accW[Ti][r] * us;
+    dw3 += __shfl_xor(dw3, 16, 64);
+    dw3 += __shfl_xor(dw3, 32, 64);
+    if (lane < 16) out[N::P_W3 + 16 * w + lane] = dw3;
+    if (tid == 0) out[N::P_B3] = db3;
+}
+
+template <class N, int LOSS>
+int launch_fcw(const PipeArgs &a, int grid, hipStream_t stream) {
+    constexpr size_t lds = fcw_lds<N>();
+    static bool attr_done[64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = -1;
+    if (dev < 0 || !attr_done[dev]) {
+        hipError_t e = hipFuncSetAttribute((const void *)fcw_fused_kernel<N, LOSS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+        if (dev >= 0) attr_done[dev] = true;
+    }
+    hipLaunchKernelGGL((fcw_fused_kernel<N, LOSS>), dim3(grid), dim3(kFcwThreads), lds, stream, a);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? LTR_OK : (int)e;
+}

@@ -95,7 +95,10 @@ struct NetT {
     static constexpr int W1H_OFF = W3_OFF + NT2 * 16 + 16;
     static constexpr int W2H_OFF = W1H_OFF + KP1 * NT1 * 512;
     static constexpr int W2TH_OFF = W2H_OFF + (TWO_ ? 0 : KP2 * NT2 * 512);
-    static constexpr int PACKED = W2TH_OFF + (TWO_ ? 0 : KPT * NT1 * 512);
+    // two-layer nets: the same W1 once more as B-fragments of the feature-partitioned kernel (ltr_fcw.h):
+    // [hidden tile][k-step][hi, lo][64 lanes][8 halfs], lane (i, g) = W1aug[16 tile + i][32 P + 8 g + j]
+    static constexpr int W1B_OFF = W2TH_OFF + (TWO_ ? 0 : KPT * NT1 * 512);
+    static constexpr int PACKED = W1B_OFF + (TWO_ ? KP1 * NT1 * 512 : 0);
     // 1 / scale of W1aug, W2aug, W2 ride in the spare floats of the w3 section: packed[W3_OFF + NT2*16 + 4 .. + 6]
 #else
     static constexpr int PACKED = W3_OFF + NT2 * 16 + 16;
@@ -401,7 +404,10 @@ __device__ __forceinline__ void gemm_wx_hl(const float *sec, float *Wb, int w, i
 
 // Activation (+ dropout) on accumulator tiles; features >= H forced to 0 (only the partial last tile needs it).
 // ReLU + Dropout(0.5): 2*max(v,0) AND-ed with a 0 / ~0 mask made from the keep bit (4 VALU ops per value).
-template <int ACT, int H, int NT, int NMAX>
+// GENP: the kernel also carries the 16-bit-per-unit stream of dropout probabilities other than 0.5 (forward-only kernels: they
+// have the registers; the fused / recomputing kernels are compiled for p = 0.5 -- 2.5 % on the f16x2 headline otherwise -- and
+// other probabilities run through ltr_mlp_forward_save / ltr_mlp_backward_saved, where the backward needs no stream at all).
+template <int ACT, int H, int NT, bool GENP, int NMAX>
 __device__ __forceinline__ void activate(f32x4 (&h)[NMAX], int q, const PipeArgs &a, int layer, const uint8_t *keep,
                                          long long doc) {
     const bool in_range = doc < a.n_docs;
@@ -416,7 +422,7 @@ __device__ __forceinline__ void activate(f32x4 (&h)[NMAX], int q, const PipeArgs
                 if (in_range && n0 < H) bytes = *reinterpret_cast<const unsigned *>(keep + doc * H + n0);
                 kb = ((bytes & 0xFFu) ? 1u : 0u) | ((bytes & 0xFF00u) ? 2u : 0u) | ((bytes & 0xFF0000u) ? 4u : 0u) |
                      ((bytes & 0xFF000000u) ? 8u : 0u);
-            } else if (a.drop_thr16) {      // any p: 16 hash bits per unit (stream layer + 2, word = unit pair)
+            } else if (GENP && a.drop_thr16) {      // any p: 16 hash bits per unit (stream layer + 2, word = unit pair)
                 const unsigned w0 = keep_word(a.seed, layer + 2, doc, 8 * To + 2 * q), w1 = keep_word(a.seed, layer + 2, doc, 8 * To + 2 * q + 1);
                 kb = ((w0 & 0xffffu) >= a.drop_thr16 ? 1u : 0u) | ((w0 >> 16) >= a.drop_thr16 ? 2u : 0u) |
                      ((w1 & 0xffffu) >= a.drop_thr16 ? 4u : 0u) | ((w1 >> 16) >= a.drop_thr16 ? 8u : 0u);
@@ -714,7 +720,7 @@ __device__ __forceinline__ int grow_exp(int ex, float m) {
     int e = __builtin_amdgcn_frexp_expf(m);
     e = m > 0.f ? e : -100;
     e = e < -100 ? -100 : e;
-    return __builtin_amdgcn_readfirstlane(e > ex ? e : ex);      // wave-uniform by construction: keep it in an SGPR
+    return e > ex ? e : ex;
 }
 #endif
 
@@ -803,6 +809,10 @@ __device__ __forceinline__ void dma_x_rows(const PipeArgs &a, float *Xs, long lo
     }
 }
 
+#if LTR_F16X2
+#include "ltr_fcw.h"
+#endif
+
 template <class N, int MODE, int LOSS>
 __global__ void __launch_bounds__(kThreads, 2) slate_pipeline_kernel(const PipeArgs a) {
     constexpr int LD = N::LD;
@@ -886,7 +896,7 @@ __global__ void __launch_bounds__(kThreads, 2) slate_pipeline_kernel(const PipeA
         __syncthreads();                                   // w3s is complete
         float m = 0.f;
         for (int j = lane; j < N::NT2 * 16; j += 64) m = fmaxf(m, fabsf(w3s[j]));
-        w3max = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, wave_allmax(m))));
+        w3max = wave_allmax(m);
     } else
 #endif
     if (XDMA) {   // pad columns of the X tile (ones feature at column F, zeros up to LD): constant, written once
@@ -1063,7 +1073,7 @@ __global__ void __launch_bounds__(kThreads, 2) slate_pipeline_kernel(const PipeA
 #pragma unroll
                 for (int To = 0; To < N::NT1; ++To) h1[To] = xb[To];
         }
-        if (!saved) activate<N::A1, N::H1, N::NT1>(h1, q, a, 0, a.keep1, gdoc);
+        if (!saved) activate<N::A1, N::H1, N::NT1, MODE == MODE_FWD>(h1, q, a, 0, a.keep1, gdoc);
         if (MODE == MODE_FWD && a.acts_out) {
 #pragma unroll
             for (int T = 0; T < N::NT1; ++T) *reinterpret_cast<f32x4 *>(a.acts_out + act_base + (size_t)T * 256) = h1[T];
@@ -1101,7 +1111,7 @@ __global__ void __launch_bounds__(kThreads, 2) slate_pipeline_kernel(const PipeA
             else
 #pragma unroll
                 for (int To = 0; To < N::NT2; ++To) h2[To] = h1[To];
-            activate<N::A2, N::H2, N::NT2>(h2, q, a, 1, a.keep2, gdoc);
+            activate<N::A2, N::H2, N::NT2, MODE == MODE_FWD>(h2, q, a, 1, a.keep2, gdoc);
             if (MODE == MODE_FWD && a.acts_out) {
 #pragma unroll
                 for (int T = 0; T < N::NT2; ++T)
@@ -1232,8 +1242,9 @@ __global__ void __launch_bounds__(kThreads, 2) slate_pipeline_kernel(const PipeA
             exh = grow_exp(exh, hm);
             const float dm = wave_allmax(fmaxf(fabsf(dsc[lane]), fabsf(dsc[lane + 64])));
             exd2 = grow_exp(exd2, dm * slope * w3max);
-            {   // if the scale grew, bring the accumulators along (a power of two: exact).  Branch-free -- f = 1 almost always --
-                // because a conditional update of 44 live accumulators costs more in spills than the 44 multiplies
+            if (exd2 + exh != E2) {                        // the scale grew: bring the accumulators along (exact: a power of two)
+                // (a branch-free multiply by 1 and SGPR-resident exponents cut the scratch 276 -> 248 B but moved the reloads
+                //  into the dW1 loop: 112.8 k -> 129.6 k cycles per tile, profiles/r03_variant_ab.json)
                 const float f = ldexpf(1.f, E2 - (exd2 + exh));
 #pragma unroll
                 for (int n = 0; n < N::TW2; ++n) accW2[n] *= f;
@@ -1344,7 +1355,7 @@ __global__ void __launch_bounds__(kThreads, 2) slate_pipeline_kernel(const PipeA
 #pragma unroll
             for (int i = 0; i < kWaves; ++i) dm = fmaxf(dm, exch[16 + i]);
             exd1 = grow_exp(exd1, dm);
-            {
+            if (exd1 + exx != E1) {
                 const float f = ldexpf(1.f, E1 - (exd1 + exx));
 #pragma unroll
                 for (int n = 0; n < N::TW1; ++n) accW1[n] *= f;
@@ -1545,6 +1556,10 @@ __global__ void pack_kernel(const float *__restrict__ W1, const float *__restric
         const int in = 16 * Ti + i;
         put((size_t)N::W2TH_OFF * 2, hh, (o < H2r && in < H1r) ? W2[o * H1r + in] * scl[2] : 0.f);
     }
+    for (int hh = gt; hh < (N::TWO ? N::KP1 * N::NT1 * 1024 : 0); hh += stride) {
+        const int j = hh & 7, lane = (hh >> 3) & 63, step = hh >> 10, tile = step / N::KP1, P = step % N::KP1;
+        put((size_t)N::W1B_OFF * 2, hh, w1aug(16 * tile + (lane & 15), 32 * P + 8 * (lane >> 4) + j) * scl[0]);
+    }
 #endif
     for (int e = gt; e < N::NT2 * 16 + 16; e += stride) {
         float v = e < H2r ? w3[e] : (e == N::NT2 * 16 ? b3[0] : 0.f);
@@ -1628,6 +1643,15 @@ int pipeline_dispatch(int mode, const PipeArgs &a, int grid, hipStream_t stream)
         case MODE_BWD: return launch_pipeline<N, MODE_BWD, 0>(a, grid, stream);
         case MODE_BWD_SAVED: return launch_pipeline<N, MODE_BWD_SAVED, 0>(a, grid, stream);
         default:
+#if LTR_F16X2
+            if constexpr (N::TWO) {      // two-layer nets: the feature-partitioned kernel, two workgroups per CU (ltr_fcw.h)
+                switch (a.loss_kind) {
+                    case 0: return launch_fcw<N, 0>(a, grid, stream);
+                    case 1: return launch_fcw<N, 1>(a, grid, stream);
+                    default: return launch_fcw<N, 2>(a, grid, stream);
+                }
+            }
+#endif
             switch (a.loss_kind) {
                 case 0: return launch_pipeline<N, MODE_FUSED, 0>(a, grid, stream);
                 case 1: return launch_pipeline<N, MODE_FUSED, 1>(a, grid, stream);
@@ -1648,6 +1672,15 @@ int ltr_net_info(int net, int32_t *info) {
                       info[4] = NET::PACKED, info[5] = NET::PART, info[7] = (int32_t)pipeline_lds<NET>()))
     info[6] = kTileDocs;
     return LTR_OK;
+}
+
+int ltr_fused_grid(int net, int n_cus) {
+    if (n_cus < 1) return LTR_ERR_PARAM;
+    if (net < LTR_NET_DOUBLE || net > LTR_NET_TWO_LAYER_64H) return LTR_ERR_PARAM;
+#if LTR_F16X2
+    if (net == LTR_NET_TWO_LAYER_64H) return 2 * n_cus;       /* 256-thread workgroups, two per CU */
+#endif
+    return n_cus;
 }
 
 int ltr_dropout_keep_mask_p(uint64_t seed, int layer, int64_t n_docs, int H, float p, uint8_t *out, void *stream) {
@@ -1757,6 +1790,7 @@ int ltr_mlp_backward(int net, const float *X, int64_t n_docs, const float *packe
     if (grid < 1) return LTR_ERR_PARAM;
     a.dscores_in = dscores;
     a.partials = partials;
+    if (a.dropout && a.drop_thr16 && !keep1) return LTR_ERR_PARAM;     /* p != 0.5: ltr_mlp_forward_save / ltr_mlp_backward_saved */
     LTR_FOR_NET(net, return pipeline_dispatch<NET>(MODE_BWD, a, grid, (hipStream_t)stream))
     return LTR_ERR_PARAM;
 }
@@ -1835,6 +1869,7 @@ int ltr_fused_step(int net, int loss_kind, const float *X, const float *labels, 
     a.pad = pad;
     a.gscale = grad_scale;
     a.apply_sigmoid = apply_sigmoid;
+    if (a.dropout && a.drop_thr16 && !keep1) return LTR_ERR_PARAM;     /* p != 0.5: the three-launch path */
     LTR_FOR_NET(net, return pipeline_dispatch<NET>(MODE_FUSED, a, grid, (hipStream_t)stream))
     return LTR_ERR_PARAM;
 }
@@ -1865,6 +1900,7 @@ int ltr_fused_step_lambda(int net, const float *X, const float *labels, int B, i
     a.lp.eps = eps;
     a.lp.log_scale = log_base == LTR_LOG_BINARY ? (float)(1.0 / 0.693147180559945309417) : 1.f;
     a.lp.log_floor = log_base == LTR_LOG_BINARY ? log2f(eps) : logf(eps);
+    if (a.dropout && a.drop_thr16 && !keep1) return LTR_ERR_PARAM;     /* p != 0.5: the three-launch path */
     LTR_FOR_NET(net, return pipeline_dispatch<NET>(MODE_FUSED, a, grid, (hipStream_t)stream))
     return LTR_ERR_PARAM;
 }

@@ -4,6 +4,7 @@ from ctypes import c_float, c_int, c_int64, c_uint64, c_void_p
 P = c_void_p
 PROTOTYPES = {
     "ltr_net_info": (c_int, [c_int, P]),
+    "ltr_fused_grid": (c_int, [c_int, c_int]),
     "ltr_mlp_pack": (c_int, [c_int, P, P, P, P, P, P, P, P]),
     "ltr_mlp_pack_sub": (c_int, [c_int, c_int, c_int, c_int, P, P, P, P, P, P, P, P]),
     "ltr_mlp_reduce_grads_sub": (c_int, [c_int, c_int, c_int, c_int, P, c_int, P, P]),

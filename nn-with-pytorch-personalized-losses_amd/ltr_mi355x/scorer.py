@@ -151,9 +151,18 @@ class _MLPScores(torch.autograd.Function):
             k1, k2 = _mask(keep1, n, info.H1, info.cH1), _mask(keep2, n, info.H2, info.cH2)
             scores = torch.empty(n, dtype=torch.float32, device=dev)
             grid = default_grid(dev, n, info.tile_docs)
-            check(lib().ltr_mlp_forward(info.net, _ptr(x2), n, _ptr(packed), int(dropout), seed, _ptr(k1), _ptr(k2),
-                                        _ptr(scores), grid, _stream()), "ltr_mlp_forward")
+            acts = None
+            if int(dropout) > 1 and k1 is None and any(p.requires_grad for p in params):
+                # a dropout probability other than 0.5: only the forward kernels carry its stream, so the forward keeps the
+                # hidden activations and the backward reads them (ltr_mlp_forward_save / ltr_mlp_backward_saved)
+                acts = torch.empty(int(lib().ltr_mlp_acts_floats(info.net, n)), dtype=torch.float32, device=dev)
+                check(lib().ltr_mlp_forward_save(info.net, _ptr(x2), n, _ptr(packed), int(dropout), seed, _ptr(k1), _ptr(k2),
+                                                 _ptr(scores), _ptr(acts), grid, _stream()), "ltr_mlp_forward_save")
+            else:
+                check(lib().ltr_mlp_forward(info.net, _ptr(x2), n, _ptr(packed), int(dropout), seed, _ptr(k1), _ptr(k2),
+                                            _ptr(scores), grid, _stream()), "ltr_mlp_forward")
         ctx.save_for_backward(x2, packed, k1, k2)
+        ctx.acts = acts
         ctx.meta = (net, int(dropout), seed, grid, [p.dtype for p in params])
         return scores.view(*x.shape[:-1], 1)
 
@@ -168,8 +177,12 @@ class _MLPScores(torch.autograd.Function):
             gs = g.detach().reshape(-1).to(torch.float32).contiguous()
             partials = torch.empty(grid * info.partial_floats, dtype=torch.float32, device=dev)
             flat = torch.empty(info.n_params, dtype=torch.float32, device=dev)
-            check(lib().ltr_mlp_backward(info.net, _ptr(x2), n, _ptr(packed), dropout, seed, _ptr(k1), _ptr(k2), _ptr(gs),
-                                         _ptr(partials), grid, _stream()), "ltr_mlp_backward")
+            if ctx.acts is not None:
+                check(lib().ltr_mlp_backward_saved(info.net, _ptr(x2), n, _ptr(packed), dropout, _ptr(ctx.acts), _ptr(gs), _ptr(partials),
+                                                   grid, _stream()), "ltr_mlp_backward_saved")
+            else:
+                check(lib().ltr_mlp_backward(info.net, _ptr(x2), n, _ptr(packed), dropout, seed, _ptr(k1), _ptr(k2), _ptr(gs),
+                                             _ptr(partials), grid, _stream()), "ltr_mlp_backward")
             reduce_grads(info, partials, grid, flat)
         grads, off = [], 0
         for shape, dt in zip(info.shapes, dtypes):
@@ -256,7 +269,7 @@ class FusedRanker:
         require_device(*self.params)
         dev = self.params[0].device
         self.device = dev
-        self.grid = int(grid) if grid else cu_count(dev)
+        self.grid = int(grid) if grid else int(lib().ltr_fused_grid(self.net, cu_count(dev)))     # persistent workgroups (1 or 2 per CU)
         # one flat fp32 buffer [all parameter gradients | loss | normaliser]: the ONLY thing data parallel all-reduces.
         # `flat` = [grads | loss] (what the optimizer and callers read); `flat_ext` adds the normaliser slot of the
         # deferred-normalisation protocol (step(defer_norm=True) -> all-reduce(flat_ext) -> finish_norm()): the local
@@ -327,7 +340,7 @@ class FusedRanker:
                              "the all-reduce: under data parallel call step(defer_norm=True) (QueryShardedTrainer does)")
         # one launch when the slate tiles a 128-document super-tile; otherwise forward launch + loss kernel +
         # backward launch -- same flat gradient buffer either way
-        one_launch = S in (32, 64, 128)
+        one_launch = S in (32, 64, 128)       # (and the reference's dropout probability: see below)
         if B == 0:
             # no slates on this rank: zero gradient contribution; the loss of an empty batch is what the
             # reference's reduction gives (mean of nothing = nan, sum of nothing = 0) unless a global batch is set
@@ -363,7 +376,7 @@ class FusedRanker:
                 self._slate = torch.empty(B, dtype=torch.float32, device=self.device)
             pack_params(self.info.handle, self.params, out=self.packed)
             h = lib()
-            if not one_launch:
+            if not one_launch or (dropout > 1 and k1 is None):     # p != 0.5: only the forward kernels carry that stream
                 out = self._step_three_launches(h, x2, yy, B, S, dropout, int(seed) & _MASK64, k1, k2, scale, lambda_mean,
                                                 defer_norm)
                 self._bind_grads()
