@@ -43,6 +43,30 @@ gather_rows_kernel(const f32x4 *__restrict__ src, const int64_t *__restrict__ id
     }
 }
 
+// Wide rows (a whole query: 128 x 136 floats = 69 632 B): one workgroup moves a 16 KiB piece of ONE row -- the row index is read
+// once per workgroup (scalar), every lane streams 4 x 16 B with no per-element division, loads issued before the stores.
+constexpr int kGatherPiece = kGatherThreads * 4;      // float4s per workgroup
+__global__ void __launch_bounds__(kGatherThreads)
+gather_rows_wide_kernel(const f32x4 *__restrict__ src, const int64_t *__restrict__ idx, int64_t n_rows, int64_t src_rows, int row_f4,
+                        int pieces, f32x4 *__restrict__ dst) {
+    for (int64_t b = blockIdx.x; b < n_rows * pieces; b += gridDim.x) {
+        const int64_t r = b / pieces;
+        const int piece = (int)(b - r * pieces);
+        const int64_t srow = idx[r];
+        if (srow < 0 || srow >= src_rows) continue;
+        const f32x4 *sp = src + srow * row_f4;
+        f32x4 *dp = dst + r * row_f4;
+        const int c0 = piece * kGatherPiece + threadIdx.x;
+        f32x4 v[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (c0 + k * kGatherThreads < row_f4) v[k] = __builtin_nontemporal_load(sp + c0 + k * kGatherThreads);
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (c0 + k * kGatherThreads < row_f4) __builtin_nontemporal_store(v[k], dp + c0 + k * kGatherThreads);
+    }
+}
+
 __global__ void __launch_bounds__(kGatherThreads)
 gather_rows_scalar_kernel(const float *__restrict__ src, const int64_t *__restrict__ idx, int64_t n_rows, int64_t src_rows,
                           int row_f, float *__restrict__ dst) {
@@ -219,7 +243,13 @@ int ltr_gather_rows_f32(const float *src, int64_t src_rows, const int64_t *idx, 
     const int64_t total = vec ? n_rows * (row_floats / 4) : n_rows * row_floats;
     int64_t blocks = (total + kGatherThreads - 1) / kGatherThreads;
     if (blocks > 256 * 32) blocks = 256 * 32;                      // 32 workgroups per CU, grid-stride beyond
-    if (vec)
+    if (vec && row_floats / 4 >= kGatherPiece / 2) {
+        const int row_f4 = (int)(row_floats / 4), pieces = (row_f4 + kGatherPiece - 1) / kGatherPiece;
+        int64_t wg = n_rows * pieces;
+        if (wg > 256 * 64) wg = 256 * 64;
+        hipLaunchKernelGGL(gather_rows_wide_kernel, dim3((unsigned)wg), dim3(kGatherThreads), 0, (hipStream_t)stream,
+                           reinterpret_cast<const f32x4 *>(src), idx, n_rows, src_rows, row_f4, pieces, reinterpret_cast<f32x4 *>(dst));
+    } else if (vec)
         hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)blocks), dim3(kGatherThreads), 0, (hipStream_t)stream,
                            reinterpret_cast<const f32x4 *>(src), idx, n_rows, src_rows, (int)(row_floats / 4),
                            reinterpret_cast<f32x4 *>(dst));

@@ -33,26 +33,37 @@ def _unbound():
     raise UnboundLocalError("local variable 'mat' referenced before assignment")
 
 
+def _systems(p_pred, p_base, p_ideal):
+    """[n_systems, B, S]: the model, the baseline rankers, optionally the ideal ranking -- ONE tensor, so that the effectiveness
+    transformation below is one set of launches for all systems instead of one set per system."""
+    parts = [p_pred.unsqueeze(0)]
+    if p_base is not None:
+        p_base.shape[2]                         # a single baseline was squeezed away by _probs: IndexError, like the reference (:26)
+        parts.append(p_base.permute(2, 0, 1))
+    if p_ideal is not None:
+        parts.append(p_ideal.unsqueeze(0))
+    return parts[0] if len(parts) == 1 else torch.cat(parts, 0)
+
+
+def _effectiveness(ref, sys3, lt):
+    """Per (system, query) effectiveness against `ref` [B, S] (:16-49, :71-117): 1 = squared differences summed over the slate,
+    2 = cosine similarity, 3 = squared difference of the dot products."""
+    if lt == 1:
+        return torch.sum((sys3 - ref) ** 2, dim=2)
+    if lt == 2:
+        return F.cosine_similarity(ref.unsqueeze(0).expand_as(sys3), sys3, dim=2)
+    return (torch.sum(sys3, dim=2) - torch.sum(ref, dim=1)) ** 2
+
+
 def _listnet_mat(p_true, p_pred, p_base, lt, add_ideal):
     """Queries x systems matrix of the Listnet-type losses (:16-49, :136-169)."""
-    if lt == 1:
-        t2 = p_true * p_true
-        eff = lambda p: (p_true * p - t2) ** 2                                              # noqa: E731
-    elif lt == 2:
-        eff = lambda p: _cos(p_true, p)                                                     # noqa: E731
-    elif lt == 3:
-        t2 = torch.sum(p_true * p_true, dim=1)
-        eff = lambda p: (torch.sum(p_true * p, dim=1) - t2) ** 2                            # noqa: E731
-    else:
+    if lt not in (1, 2, 3):
         _unbound()
-    mat = [eff(p_pred)]
-    if p_base is not None:
-        mat += [eff(p_base[:, :, i]) for i in range(p_base.shape[2])]
-    if add_ideal == 2:
-        mat.append(eff(p_true))
-    mat = torch.stack(mat)
-    if lt == 1:
-        mat = torch.sum(mat, dim=2)
+    sys3 = _systems(p_pred, p_base, p_true if add_ideal == 2 else None)
+    if lt == 2:
+        mat = _effectiveness(p_true, sys3, 2)
+    else:                        # 1: (p_true p - p_true^2)^2 summed over the slate; 3: (sum p_true p - sum p_true^2)^2
+        mat = _effectiveness(p_true * p_true, p_true * sys3, lt)
     mat = mat.t()
     if lt == 1 or lt == 3:       # larger distance = worse: flip so that larger = better (:47-49)
         mat = -mat + torch.max(mat)
@@ -61,23 +72,26 @@ def _listnet_mat(p_true, p_pred, p_base, lt, add_ideal):
 
 def _lambda_mat(p_true, p_pred, p_base, lt, add_ideal, scheme, ideal_is_ones):
     """Queries x systems matrix of the Lambda-type losses (:71-117, :191-236): effectiveness from the column sums of
-    lambdaMask(p, p_true, weighing_scheme, return_losses=True)."""
+    lambdaMask(p, p_true, weighing_scheme, return_losses=True).  Three colsum launches whatever the number of systems: the ideal
+    ranking, the model (the one that carries a gradient), and ALL baselines as one [n_base * B, S] batch."""
     if lt not in (1, 2):
         _unbound()
-    cs = lambda p: _risk.lambda_colsum(p, p_true, scheme)                                   # noqa: E731
-    tt = cs(p_true)
-    eff = (lambda c: (c - tt) ** 2) if lt == 1 else (lambda c: _cos(tt, c))                 # noqa: E731
-    mat = [eff(cs(p_pred))]
-    if p_base is not None:
-        mat += [eff(cs(p_base[:, :, i].contiguous())) for i in range(p_base.shape[2])]
-    if add_ideal == 2:
-        if lt == 2 and ideal_is_ones:
-            mat.append(torch.ones(tt.shape[0], dtype=torch.float, device=tt.device))        # :106
-        else:
-            mat.append(eff(tt))
-    mat = torch.stack(mat)
-    if lt == 1:
-        mat = torch.sum(mat, dim=2)
+    B, S = p_true.shape
+    with torch.no_grad():
+        tt = _risk.lambda_colsum(p_true, p_true, scheme)
+        cb = None
+        if p_base is not None:
+            nb = p_base.shape[2]                # (IndexError for a single, squeezed baseline: like the reference, :79)
+            stacked = p_base.permute(2, 0, 1).reshape(nb * B, S).contiguous()
+            cb = _risk.lambda_colsum(stacked, p_true.repeat(nb, 1), scheme).view(nb, B, S)
+    cp = _risk.lambda_colsum(p_pred, p_true, scheme)
+    parts = [cp.unsqueeze(0)] + ([cb] if cb is not None else [])
+    ones_col = add_ideal == 2 and lt == 2 and ideal_is_ones
+    if add_ideal == 2 and not ones_col:
+        parts.append(tt.unsqueeze(0))
+    mat = _effectiveness(tt, parts[0] if len(parts) == 1 else torch.cat(parts, 0), lt)
+    if ones_col:
+        mat = torch.cat([mat, torch.ones((1, B), dtype=mat.dtype, device=mat.device)], 0)            # :106
     mat = mat.t()
     if lt == 1:
         mat = -mat + torch.max(mat)
