@@ -99,7 +99,8 @@ def _lambda_mat(p_true, p_pred, p_base, lt, add_ideal, scheme, ideal_is_ones):
 
 
 def _factor(negative, like):
-    return torch.tensor([negative], requires_grad=True, dtype=torch.float, device=like.device)
+    # (a fill kernel, not a host-to-device copy: the whole loss can then be captured in a hipGraph -- ltr_mi355x.graphs)
+    return torch.full((1,), float(negative), dtype=torch.float, device=like.device, requires_grad=True)
 
 
 def _by_strategy(risk, mat, alpha, return_strategy, factor):

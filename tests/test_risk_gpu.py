@@ -146,3 +146,27 @@ def test_risk_loss_errors_and_larger_batch(dev):
         oo.sum().backward()
         assert relerr(out.detach().cpu().numpy(), oo.detach().numpy()) < 5e-5
         assert relerr(x.grad.cpu().numpy(), xo.grad.numpy()) < 5e-5
+
+
+def test_graphed_risk_loss_replays_the_eager_step_bit_for_bit():
+    """ltr_mi355x.graphs.GraphedLoss: forward + backward of a risk loss captured once into a hipGraph (ctypes launches of this
+    package + ATen glue), replayed on new values: identical to the eager call on those values."""
+    from losses.riskLosses import riskLosses as RL
+    from ltr_mi355x.graphs import GraphedLoss
+    dev = torch.device("cuda:0")
+    gen = torch.Generator().manual_seed(99)
+    B, S, nb = 12, 40, 3
+    mk = lambda: (torch.randn(B, S, generator=gen).to(dev), torch.randint(0, 5, (B, S), generator=gen).float().to(dev),
+                  torch.randn(B, S, nb, generator=gen).to(dev))                                      # noqa: E731
+    for fn in (lambda yp, yt, yb: RL.geoRiskLambdaLoss(yp, yt, yb, listnet_transformation=2),
+               lambda yp, yt, yb: RL.zRiskListnetLoss(yp, yt, yb, listnet_transformation=1, return_strategy=2, add_ideal_ranking_to_mat=2)):
+        step = GraphedLoss(fn, mk())
+        for _ in range(3):
+            yp, yt, yb = mk()
+            loss, (g,) = step(yp, yt, yb)
+            ype = yp.clone().requires_grad_(True)
+            want = fn(ype, yt, yb)
+            (gw,) = torch.autograd.grad(want.sum(), [ype])
+            assert torch.equal(loss.detach(), want.detach()) and torch.equal(g, gw)
+    with pytest.raises(ValueError):
+        step(yp[:5], yt[:5], yb[:5])

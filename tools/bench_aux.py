@@ -54,6 +54,9 @@ def main():
             RL.geoRiskLambdaLoss(ypd, ytd, ybd, listnet_transformation=2).sum().backward()
         rec = {"row": "f-1", "what": f"geoRiskLambdaLoss fwd+bwd, B={B}, S={S}, {nb} baselines (5 lambdaMask column sums + geoRisk)",
                "gpu_ms": round(gpu_ms(dev_step), 3)}
+        from ltr_mi355x.graphs import GraphedLoss
+        graphed = GraphedLoss(lambda a_, b_, c_: RL.geoRiskLambdaLoss(a_, b_, c_, listnet_transformation=2), (ypd.detach(), ytd, ybd))
+        rec["gpu_ms_hipgraph"] = round(gpu_ms(lambda: graphed(ypd.detach(), ytd, ybd)), 3)
         if B <= 100:
             x = yp.clone().requires_grad_(True)
 
