@@ -15,6 +15,11 @@
 
 namespace ltr {
 
+// 1 / x on the hardware reciprocal (v_rcp_f32, 1 ulp).  NOT __frcp_rn: without fast-math hipcc expands that to the correctly
+// rounded IEEE division sequence (v_div_scale, v_rcp, four fma, v_div_fmas, v_div_fixup: an 11-instruction dependent chain) --
+// which is what sat in the inner loop of every pair sweep until round 3 (profiles/r03_variant_ab.json).
+__device__ __forceinline__ float ltr_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+
 struct SlateGroup {
     int S;      // documents in the slate
     int group;  // threads cooperating on the slate
@@ -162,7 +167,7 @@ __device__ __forceinline__ SlateGroup make_group(int S, int group, float *scratc
 // precision on the small side (small = e * big, e = exp(-|x|)).
 __device__ __forceinline__ void sigmoid_pair(float x, float &s_pos, float &s_neg) {
     float e = __expf(-fabsf(x));
-    float r = __frcp_rn(1.f + e);
+    float r = ltr_rcp(1.f + e);
     float big = r, small = e * r;
     bool nonneg = x >= 0.f;
     s_pos = nonneg ? big : small;   // sigmoid(x)

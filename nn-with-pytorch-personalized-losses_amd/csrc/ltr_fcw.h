@@ -187,7 +187,7 @@ __global__ void __launch_bounds__(kFcwThreads, 2) fcw_fused_kernel(const PipeArg
             for (int r = 0; r < 4; ++r) {
                 float v = h1[T][r] * un;
                 if (N::A1 == ACT_RELU_DROP) v = fmaxf(v, 0.f);
-                else if (N::A1 == ACT_SIGMOID) v = __frcp_rn(1.f + __expf(-v));
+                else if (N::A1 == ACT_SIGMOID) v = __frcp_rn(1.f + __expf(-v))      /* correctly rounded: h (1 - h) of the backward cancels when h is near 1 */;
                 h1[T][r] = v;
             }
         if (drop) {      // (uniform) training-mode dropout: its own loop, so that the hash arithmetic does not sit in the common path

@@ -441,7 +441,7 @@ __device__ __forceinline__ void activate(f32x4 (&h)[NMAX], int q, const PipeArgs
                     v = __builtin_bit_cast(float, __builtin_bit_cast(int, v * a.drop_scale) & m);   // p = 0.5: v * 2 == v + v
                 }
             } else if (ACT == ACT_SIGMOID) {
-                v = __frcp_rn(1.f + __expf(-v));
+                v = __frcp_rn(1.f + __expf(-v))      /* correctly rounded: h (1 - h) of the backward cancels when h is near 1 */;
             }
             if (16 * To + 16 > H) v = (16 * To + 4 * q + r < H) ? v : 0.f;      // compile-time: last tile only
             h[To][r] = v;

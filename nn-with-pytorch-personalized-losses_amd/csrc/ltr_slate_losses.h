@@ -172,7 +172,7 @@ __device__ __forceinline__ float approx_ndcg_slate(const SlateGroup &g, float *s
                     const lds_f2 N = na * db + nb * da;                                          // (N01, N23)
                     const float den = D[0] * D[1];
                     const float num = fmaf(N[0], D[1], N[1] * D[0]);
-                    acc[(j >> 2) & 1] = fmaf(num, __frcp_rn(den), acc[(j >> 2) & 1]);
+                    acc[(j >> 2) & 1] = fmaf(num, ltr_rcp(den), acc[(j >> 2) & 1]);
                 }
                 p = acc[0] + acc[1];
                 if (i >= j0 && i < j1) p -= 0.5f;                                               // the j == i term: u_i / (2 u_i)
@@ -211,18 +211,18 @@ __device__ __forceinline__ float approx_ndcg_slate(const SlateGroup &g, float *s
                 for (int j = j0; j < j1; j += 4) {
                     const lds_f4 u = *reinterpret_cast<const lds_f4 *>(uu + j);
                     const lds_f4 m = *reinterpret_cast<const lds_f4 *>(mk + j);
-                    p0 = fmaf(m[0], fmaxf(u[0] * __frcp_rn(ui + u[0]), eps), p0);
-                    p1 = fmaf(m[1], fmaxf(u[1] * __frcp_rn(ui + u[1]), eps), p1);
-                    p2 = fmaf(m[2], fmaxf(u[2] * __frcp_rn(ui + u[2]), eps), p2);
-                    p3 = fmaf(m[3], fmaxf(u[3] * __frcp_rn(ui + u[3]), eps), p3);
+                    p0 = fmaf(m[0], fmaxf(u[0] * ltr_rcp(ui + u[0]), eps), p0);
+                    p1 = fmaf(m[1], fmaxf(u[1] * ltr_rcp(ui + u[1]), eps), p1);
+                    p2 = fmaf(m[2], fmaxf(u[2] * ltr_rcp(ui + u[2]), eps), p2);
+                    p3 = fmaf(m[3], fmaxf(u[3] * ltr_rcp(ui + u[3]), eps), p3);
                 }
                 p = (p0 + p1) + (p2 + p3);
-                if (i >= j0 && i < j1) p -= fmaxf(ui * __frcp_rn(ui + ui), eps);   // the j == i term
+                if (i >= j0 && i < j1) p -= fmaxf(ui * ltr_rcp(ui + ui), eps);   // the j == i term
             } else {
                 const float si = sc[i];
                 for (int j = j0; j < j1; ++j) {
                     const float e = __expf(alpha * (si - sc[j]));
-                    const float c = fmaxf(__frcp_rn(1.f + e), eps);
+                    const float c = fmaxf(ltr_rcp(1.f + e), eps);
                     p += (j != i && mk[j] != 0.f) ? c : 0.f;
                 }
             }
@@ -233,13 +233,13 @@ __device__ __forceinline__ float approx_ndcg_slate(const SlateGroup &g, float *s
         if (ultra) {
             // per-row epilogue on the hardware transcendentals (v_log_f32 / v_rcp_f32, 1 ulp each): the IEEE log2f / division
             // sequences of the general path are ~100 instructions per row, executed by every wave of the workgroup
-            if (row && g.cg == 0 && cnt > 0.f) idcg_acc = fmaf(cnt, __frcp_rn(__log2f(2.f + (float)i)), idcg_acc);
+            if (row && g.cg == 0 && cnt > 0.f) idcg_acc = fmaf(cnt, ltr_rcp(__log2f(2.f + (float)i)), idcg_acc);
             if (vi && g.cg == 0) {
                 const float gain = gn[i];
-                const float iL = __frcp_rn(__log2f(1.f + pos));
+                const float iL = ltr_rcp(__log2f(1.f + pos));
                 const float gl = gain * iL;
                 loss_acc += gl;
-                gg[i] = gl * iL * __frcp_rn((1.f + pos) * LTR_LN2);    // d(-sum gain/L)/d pos_i, not yet / maxDCG
+                gg[i] = gl * iL * ltr_rcp((1.f + pos) * LTR_LN2);    // d(-sum gain/L)/d pos_i, not yet / maxDCG
             }
         } else if (vi && g.cg == 0) {
             const float gain = gn[i];
@@ -295,7 +295,7 @@ __device__ __forceinline__ float approx_ndcg_slate(const SlateGroup &g, float *s
                 const lds_f2 N = ta * db + tb * da;                                              // (N01, N23)
                 const float den = Q[0] * Q[1];
                 const float num = fmaf(N[0], Q[1], N[1] * Q[0]);
-                acc[(j >> 2) & 1] = fmaf(num, __frcp_rn(den), acc[(j >> 2) & 1]);
+                acc[(j >> 2) & 1] = fmaf(num, ltr_rcp(den), acc[(j >> 2) & 1]);
             }
             a = uk * (acc[0] + acc[1]);
         } else if (vk) {
@@ -310,7 +310,7 @@ __device__ __forceinline__ float approx_ndcg_slate(const SlateGroup &g, float *s
                     const lds_f4 gj = *reinterpret_cast<const lds_f4 *>(gg + j);
 #define LTR_PAIR(e, acc)                                                            \
     {                                                                               \
-        const float r = __frcp_rn(uk + u[e]);                                       \
+        const float r = ltr_rcp(uk + u[e]);                                       \
         const float ckj = u[e] * r, cjk = uk * r;                                   \
         const float term = (cjk >= eps ? gj[e] : 0.f) - (ckj >= eps ? gk : 0.f);    \
         acc = fmaf(m[e] * (ckj * cjk), term, acc);                                  \
@@ -323,7 +323,7 @@ __device__ __forceinline__ float approx_ndcg_slate(const SlateGroup &g, float *s
                 const float sk = sc[k];
                 for (int j = j0; j < j1; ++j) {
                     const float e = __expf(alpha * (sk - sc[j]));
-                    const float ckj = __frcp_rn(1.f + e);                 // sigmoid(-alpha (s_k - s_j))
+                    const float ckj = ltr_rcp(1.f + e);                 // sigmoid(-alpha (s_k - s_j))
                     const float cjk = (e < 1e30f) ? e * ckj : 1.f;        // sigmoid(-alpha (s_j - s_k))
                     const float term = (cjk >= eps ? gg[j] : 0.f) - (ckj >= eps ? gk : 0.f);
                     a += (j != k && mk[j] != 0.f) ? ckj * cjk * term : 0.f;
