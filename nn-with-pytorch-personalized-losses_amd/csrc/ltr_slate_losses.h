@@ -58,7 +58,6 @@ __device__ __forceinline__ float ideal_dcg(const SlateGroup &g, const float *yl,
 //     u_k = exp(alpha (s_k - mid)),   sigmoid(-alpha (s_i - s_j)) = u_j / (u_i + u_j),
 // i.e. one v_rcp per pair and no v_exp.  Wider ranges (where u would leave fp32) take the per-pair exp path.
 typedef float lds_f4 __attribute__((ext_vector_type(4)));
-typedef float lds_f2 __attribute__((ext_vector_type(2)));
 
 struct NoStamp {
     __device__ __forceinline__ void operator()(int) const {}
@@ -83,8 +82,9 @@ __device__ __forceinline__ void approx_ndcg_init(const SlateGroup &g) {
 //       histogram (LDS integer adds: exact, order-free) instead of an S^2 rank count.
 // Then FOUR pair terms share ONE v_rcp_f32:
 //   sum_k n_k / d_k  (k = 0..3)  =  (N01 D23 + N23 D01) / (D01 D23),   N01 = n0 d1 + n1 d0,  D01 = d0 d1, ...
-// which the compiler maps onto packed fp32 (v_pk_mul/add/fma_f32): 3.3 issue slots per ordered pair in sweep 1
-// (was ~13: add, rcp = 4 slots, mul, max, fma and 5 of rank counting) and 4.3 in sweep 2 (was ~14).
+// 15 plain fp32 VALU instructions + one quarter-rate v_rcp_f32 per FOUR ordered pairs in sweep 1 (~4.5 issue slots per
+// pair; was ~13: add, rcp = 4 slots, mul, max, fma and 5 of rank counting) and 23 + rcp in sweep 2.  The library is built
+// with -fno-slp-vectorize: packed fp32 (v_pk_*_f32) has no rate advantage on CDNA4 and its operand-pair moves are pure cost.
 // sweep 1:  pos_i - 1 = sum_j um_j / (u_i + u_j) - 1/2 [i real]
 // sweep 2:  d loss / d s_k = alpha u_k sum_j um_j (g_j - g_k) / (u_k + u_j)^2        (t_kj = u_k u_j / (u_k + u_j)^2)
 template <int JB = 0, int UNR = 2, class Store, class Stamp = NoStamp>
@@ -161,20 +161,25 @@ __device__ __forceinline__ float approx_ndcg_slate(const SlateGroup &g, float *s
         if (ultra) {
             if (vi) {
                 const float ui = uu[i];
-                lds_f2 acc = {0.f, 0.f};
-#pragma unroll UNR
-                for (int j = j0; j < j1; j += 4) {
+                // plain fp32 issue (packed fp32 has no rate advantage on CDNA4 and costs operand-pair moves); two independent
+                // accumulator chains, eight columns per trip
+                auto quad = [&](int j, float acc) {
                     const lds_f4 u = *reinterpret_cast<const lds_f4 *>(uu + j);
                     const lds_f4 n = *reinterpret_cast<const lds_f4 *>(xs.um + j);
-                    const lds_f2 da = {ui + u[0], ui + u[2]}, db = {ui + u[1], ui + u[3]};      // (d0,d2) (d1,d3)
-                    const lds_f2 na = {n[0], n[2]}, nb = {n[1], n[3]};
-                    const lds_f2 D = da * db;                                                    // (D01, D23)
-                    const lds_f2 N = na * db + nb * da;                                          // (N01, N23)
-                    const float den = D[0] * D[1];
-                    const float num = fmaf(N[0], D[1], N[1] * D[0]);
-                    acc[(j >> 2) & 1] = fmaf(num, ltr_rcp(den), acc[(j >> 2) & 1]);
+                    const float d0 = ui + u[0], d1 = ui + u[1], d2 = ui + u[2], d3 = ui + u[3];
+                    const float D01 = d0 * d1, D23 = d2 * d3;
+                    const float N01 = fmaf(n[0], d1, n[1] * d0), N23 = fmaf(n[2], d3, n[3] * d2);
+                    return fmaf(fmaf(N01, D23, N23 * D01), ltr_rcp(D01 * D23), acc);
+                };
+                float acc0 = 0.f, acc1 = 0.f;
+                int j = j0;
+#pragma unroll UNR
+                for (; j + 8 <= j1; j += 8) {
+                    acc0 = quad(j, acc0);
+                    acc1 = quad(j + 4, acc1);
                 }
-                p = acc[0] + acc[1];
+                if (j < j1) acc0 = quad(j, acc0);
+                p = acc0 + acc1;
                 if (i >= j0 && i < j1) p -= 0.5f;                                               // the j == i term: u_i / (2 u_i)
             }
             // ideal-DCG term of RANK i from the label histogram: the document at sorted position i has the label v with
@@ -280,24 +285,27 @@ __device__ __forceinline__ float approx_ndcg_slate(const SlateGroup &g, float *s
         float a = 0.f;
         if (vk && ultra) {
             const float gk = gg[k], uk = uu[k];
-            lds_f2 acc = {0.f, 0.f};
-#pragma unroll UNR
-            for (int j = j0; j < j1; j += 4) {
+            auto quad = [&](int j, float acc) {
                 const lds_f4 u = *reinterpret_cast<const lds_f4 *>(uu + j);
                 const lds_f4 n = *reinterpret_cast<const lds_f4 *>(xs.um + j);
                 const lds_f4 gj = *reinterpret_cast<const lds_f4 *>(gg + j);
-                lds_f2 da = {uk + u[0], uk + u[2]}, db = {uk + u[1], uk + u[3]};
-                da = da * da;                                                                    // (q0, q2)
-                db = db * db;                                                                    // (q1, q3)
-                const lds_f2 ta = lds_f2{n[0], n[2]} * (lds_f2{gj[0], gj[2]} - gk);             // (t0, t2); exactly 0 at j == k
-                const lds_f2 tb = lds_f2{n[1], n[3]} * (lds_f2{gj[1], gj[3]} - gk);             // (t1, t3)
-                const lds_f2 Q = da * db;                                                        // (Q01, Q23)
-                const lds_f2 N = ta * db + tb * da;                                              // (N01, N23)
-                const float den = Q[0] * Q[1];
-                const float num = fmaf(N[0], Q[1], N[1] * Q[0]);
-                acc[(j >> 2) & 1] = fmaf(num, ltr_rcp(den), acc[(j >> 2) & 1]);
+                float q0 = uk + u[0], q1 = uk + u[1], q2 = uk + u[2], q3 = uk + u[3];
+                q0 *= q0, q1 *= q1, q2 *= q2, q3 *= q3;
+                const float t0 = n[0] * (gj[0] - gk), t1 = n[1] * (gj[1] - gk);                 // exactly 0 at j == k
+                const float t2 = n[2] * (gj[2] - gk), t3 = n[3] * (gj[3] - gk);
+                const float Q01 = q0 * q1, Q23 = q2 * q3;
+                const float N01 = fmaf(t0, q1, t1 * q0), N23 = fmaf(t2, q3, t3 * q2);
+                return fmaf(fmaf(N01, Q23, N23 * Q01), ltr_rcp(Q01 * Q23), acc);
+            };
+            float acc0 = 0.f, acc1 = 0.f;
+            int j = j0;
+#pragma unroll UNR
+            for (; j + 8 <= j1; j += 8) {
+                acc0 = quad(j, acc0);
+                acc1 = quad(j + 4, acc1);
             }
-            a = uk * (acc[0] + acc[1]);
+            if (j < j1) acc0 = quad(j, acc0);
+            a = uk * (acc0 + acc1);
         } else if (vk) {
             const float gk = gg[k];
             if (fast) {

@@ -13,7 +13,10 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(os.path.dirname(HERE), "csrc")
 OUT = os.path.join(HERE, "libltr_mi355x.so")
-FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-shared", "-fPIC", "-fno-gpu-rdc"]
+# -fno-slp-vectorize: the SLP vectoriser turns independent fp32 chains into v_pk_*_f32 plus operand-pair moves; packed fp32
+# has no rate advantage on CDNA4, so the moves are pure cost (measured: approxNDCG S=128 115 -> 132 M slates/s, the fused
+# two-layer step 23.1 -> 25.7 M; profiles/r03_variant_ab.json)
+FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-shared", "-fPIC", "-fno-gpu-rdc", "-fno-slp-vectorize"]
 VARIANTS = {"": [], "f16x2": ["-DLTR_F16X2=1"]}
 
 
