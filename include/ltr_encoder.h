@@ -100,6 +100,15 @@ int ltr_enc_attention_fwd(const uint16_t *qkv, const uint8_t *mask, int B, int S
 int ltr_enc_attention_bwd(const uint16_t *qkv, const uint16_t *ctx, const uint16_t *dctx, const uint8_t *mask, int B, int S, int h,
                           int dk, float drop_p, uint64_t seed, int stream_id, uint16_t *dqkv, void *stream);
 
+/* The same pair with the row statistic kept between them: lse [B*h][S] fp32 = log2 sum_k 2^(log2(e) s_qk / sqrt(dk)) over the
+ * unmasked keys (+inf for a query without one), written by the forward (NULL = not wanted) and read by the backward, which
+ * then evaluates every probability ONCE, key-major (dk <= 16 and S <= 256; otherwise, or with lse == NULL, the two-phase
+ * kernel of ltr_enc_attention_bwd runs).  This is what the training step uses. */
+int ltr_enc_attention_fwd_lse(const uint16_t *qkv, const uint8_t *mask, int B, int S, int h, int dk, float drop_p,
+                              uint64_t seed, int stream_id, uint16_t *ctx, float *lse, void *stream);
+int ltr_enc_attention_bwd_lse(const uint16_t *qkv, const uint16_t *ctx, const uint16_t *dctx, const float *lse, const uint8_t *mask,
+                              int B, int S, int h, int dk, float drop_p, uint64_t seed, int stream_id, uint16_t *dqkv, void *stream);
+
 /* p_attn, the second value `attention()` returns (transformer.py:161-164; MultiHeadedAttention keeps it in `.attn`, :207):
  * probs [B][h][S][S] fp32 = dropout(softmax(q k^T / sqrt(dk) masked)), from the same bf16 q, k and the same dropout stream
  * as ltr_enc_attention_fwd.  Forward-only helper for callers that inspect the attention map; not on the training path. */

@@ -1565,6 +1565,8 @@ struct AttArgs {
     float drop_p;
     unsigned long long seed;
     int stream_id;
+    float *lse;           // [B*h][S] fp32 log2-sum-exp of the scaled scores: written by the forward when non-null, read by the
+                          // key-major backward (attention_bwd_km_kernel); nullptr = the two-phase backward recomputes it
 };
 
 // 8 consecutive head features d0 .. d0+7 of one token row (zero beyond dk / for missing rows)
@@ -1606,7 +1608,8 @@ inline unsigned att_grid(int B, int h) { return (unsigned)((B + 7) / 8 * 8 * h);
 
 // stage `which` (0 Q, 1 K, 2 V of qkv; 3 = dctx) of slate b / head hd: row image [Sp][kRowLd] and/or transposed image
 // [32][ldt].  All threads of the workgroup.
-__device__ __forceinline__ void stage_head(const AttArgs &a, int b, int hd, int which, int Sp, bf16_t *rows, bf16_t *tr, int ldt) {
+__device__ __forceinline__ void stage_head(const AttArgs &a, int b, int hd, int which, int Sp, bf16_t *rows, bf16_t *tr, int ldt,
+                                           int trch = 4) {
     const int d = a.h * a.dk;
     const bool vec = a.dk % 8 == 0;
     const bf16_t *base = which < 3 ? a.qkv + (long long)b * a.S * 3 * d + which * d + hd * a.dk
@@ -1616,7 +1619,7 @@ __device__ __forceinline__ void stage_head(const AttArgs &a, int b, int hd, int 
         const int tok = e >> 2, ch = e & 3;
         const u32x4 v = load8(base + tok * ld, 8 * ch, a.dk, vec, tok < a.S);
         if (rows) *reinterpret_cast<u32x4 *>(rows + tok * kRowLd + 8 * ch) = v;
-        if (tr) {
+        if (tr && ch < trch) {       // trch = 2: a 16-row image (dk <= 16)
 #pragma unroll
             for (int x = 0; x < 4; ++x) {
                 tr[(8 * ch + 2 * x) * ldt + tok] = (bf16_t)(v[x] & 0xffffu);
@@ -1715,6 +1718,7 @@ __global__ void __launch_bounds__(kAttThreads) attention_fwd_kernel(AttArgs a) {
             }
         float lse2;
         softmax_tile<KTMAX>(st, KT, biasS, c2, g, lse2);
+        if (a.lse && g == 0 && query < a.S) a.lse[(long long)bh * a.S + query] = lse2;
         f32x4 o[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
         for (int u = 0; u < KTMAX / 2; ++u)
@@ -1894,6 +1898,168 @@ inline size_t att_bwd_lds(int S) {
     return (size_t)(2 * Sp * kRowLd + 2 * kDkPad * tr_ld(Sp)) * sizeof(bf16_t) + (size_t)Sp * 12;
 }
 
+// ---- key-major backward in ONE pass (dk <= 16, S <= 256, the forward's lse2 saved) -------------------------------------
+// The two-phase kernel above evaluates every probability twice (S^T tiles for dQ, S tiles for dK / dV): ~57 VALU
+// instructions per (query, key) pair, which is what bounds it (SQ_INSTS_VALU 119 M per launch at config-5 shapes against
+// 3.7 M MFMAs).  Here every pair is evaluated ONCE, key-major: wave w owns KPW = KTMAX / 4 CONTIGUOUS key tiles and walks
+// all query tiles; per (query tile, key tile) it has S and dPd as [query 4g+r][key j] accumulator tiles, from which
+//   p = 2^(c2 s - lse2),  Pd = keep ? p ks : 0,  dS = p (keep ? dPd ks : 0  -  D) / sqrt(dk)
+// feed dV^T += dO^T Pd and dK^T += Q^T dS directly (contraction over queries: the accumulator layout IS the B operand),
+// while dQ^T += K^T dS^T contracts over KEYS and needs dS with the query on lane & 15: each wave writes its bf16 dS tile
+// [key][16 queries] (one ds_write_b64 per lane, 32-byte rows) and takes it back with ds_read_b64_tr_b16 as the B operand
+// (same-wave LDS ordering, no barrier).  dQ is accumulated per wave over its own keys for all query tiles (registers) and
+// the four partials are summed through LDS in wave order at the end: deterministic.
+__device__ __forceinline__ u32x4 tr_frag_bf16(const bf16_t *lane_base, int r0) {
+    typedef short s16x4_t __attribute__((ext_vector_type(4)));
+    typedef __attribute__((address_space(3))) s16x4_t *lp4;
+    const bf16_t *p = lane_base + r0 * 16;
+    const u32x2 lo = __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp4)(p)));
+    const u32x2 hi = __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp4)(p + 16 * 16)));
+    return u32x4{lo[0], lo[1], hi[0], hi[1]};
+}
+
+template <int KTMAX, bool FULL>
+__global__ void __launch_bounds__(kAttThreads, 2) attention_bwd_km_kernel(AttArgs a) {
+    constexpr int KPW = KTMAX / 4;                       // key tiles per wave
+    static_assert(KPW % 2 == 0, "32-key chunks");
+    extern __shared__ __attribute__((aligned(16))) bf16_t smem[];
+    const int Sp = round_up(a.S, 32), KT = FULL ? KTMAX : Sp / 16, ldt = tr_ld(Sp);
+    bf16_t *Qr = smem, *dOr = Qr + Sp * kRowLd, *QT = dOr + Sp * kRowLd, *dOT = QT + 16 * ldt, *KTi = dOT + 16 * ldt;
+    bf16_t *Tq = KTi + 16 * ldt;                                                   // [4 waves][16 KPW keys][16 queries]
+    float *lseS = reinterpret_cast<float *>(Tq + 4 * 16 * KPW * 16), *DS = lseS + Sp, *biasS = DS + Sp;
+    int b, hd;
+    if (!att_slate_head(a.B, a.h, b, hd)) return;
+    const int d = a.h * a.dk, bh = b * a.h + hd;
+    const int lane = threadIdx.x & 63, j = lane & 15, g = lane >> 4;
+    const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) & 3;        // wave-uniform (scalar branches below)
+    const bool vec = a.dk % 8 == 0;
+    const float scale = 1.f / sqrtf((float)a.dk), c2 = 1.44269504088896341f * scale;
+    const unsigned thr = drop_threshold(a.drop_p);
+    const float ks = thr ? 1.f / (1.f - a.drop_p) : 1.f, kss = ks * scale;
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+
+    stage_head(a, b, hd, 0, Sp, Qr, QT, ldt, 2);
+    stage_head(a, b, hd, 3, Sp, dOr, dOT, ldt, 2);
+    stage_head(a, b, hd, 1, Sp, nullptr, KTi, ldt, 2);
+    for (int q = threadIdx.x; q < Sp; q += kAttThreads) {
+        biasS[q] = q >= a.S || (a.mask && a.mask[(long long)b * a.S + q] == 1) ? -INFINITY : 0.f;
+        float D = 0.f;
+        if (q < a.S) {
+            const long long tok = (long long)b * a.S + q;
+            const bf16_t *dr = a.dctx + tok * d + hd * a.dk, *orow = a.ctx + tok * d + hd * a.dk;
+            if (vec) {
+                for (int x = 0; x < a.dk; x += 8)
+                    D += dot8(*reinterpret_cast<const u32x4 *>(dr + x), *reinterpret_cast<const u32x4 *>(orow + x));
+            } else {
+                for (int x = 0; x < a.dk; ++x) D += from_bf16(dr[x]) * from_bf16(orow[x]);
+            }
+        }
+        DS[q] = D * scale;
+        lseS[q] = q < a.S ? a.lse[(long long)bh * a.S + q] : INFINITY;     // padded queries: p = 0
+    }
+    // this wave's keys: B operands of S = Q K^T and dPd = dO V^T straight from global memory
+    u32x4 kf[KPW], vf[KPW];
+    bool msk[KPW];
+#pragma unroll
+    for (int c = 0; c < KPW; ++c) {
+        const int key = 16 * (w * KPW + c) + j;
+        const long long tok = (long long)b * a.S + key;
+        kf[c] = load8(a.qkv + tok * 3 * d + d + hd * a.dk, 8 * g, a.dk, vec, key < a.S);
+        vf[c] = load8(a.qkv + tok * 3 * d + 2 * d + hd * a.dk, 8 * g, a.dk, vec, key < a.S);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < KPW; ++c) {
+        const int key = 16 * (w * KPW + c) + j;
+        msk[c] = key < Sp ? biasS[key] != 0.f : true;
+    }
+    bf16_t *Tw = Tq + w * 16 * KPW * 16;
+    const bf16_t *Tlane = Tw + (4 * g + (j >> 2)) * 16 + 4 * (j & 3);
+    f32x4 dv[KPW], dkk[KPW], dq[KTMAX];
+#pragma unroll
+    for (int c = 0; c < KPW; ++c) dv[c] = dkk[c] = zero;
+#pragma unroll
+    for (int qt = 0; qt < KTMAX; ++qt) dq[qt] = zero;
+
+#pragma unroll
+    for (int u2 = 0; u2 < KTMAX / 2; ++u2)
+        if (2 * u2 < KT) {
+            unsigned pk[KPW][4], dsk[KPW][4];
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                const int qt = 2 * u2 + half;
+                const u32x4 qa = row_frag(Qr, qt, lane), da = row_frag(dOr, qt, lane);
+                const f32x4 l4 = *reinterpret_cast<const f32x4 *>(lseS + 16 * qt + 4 * g);
+                const f32x4 d4 = *reinterpret_cast<const f32x4 *>(DS + 16 * qt + 4 * g);
+#pragma unroll
+                for (int c = 0; c < KPW; ++c) {       // key tiles past the slate run too (masked: p = 0) -- no per-tile branches
+                        const f32x4 s = mfma_bf16(qa, kf[c], zero);          // S[query 16 qt + 4 g + r][key]
+                        const f32x4 dpd = mfma_bf16(da, vf[c], zero);        // dPd[query][key]
+                        const unsigned keep4 = thr ? drop_keep_col4(a.seed, a.stream_id, attn_idx(bh, Sp, 16 * qt + 4 * g, 16 * (w * KPW + c) + j),
+                                                                    (unsigned long long)Sp, thr, lane) : 15u;
+                        f32x4 pd, ds;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const float p = msk[c] ? 0.f : __builtin_amdgcn_exp2f(fmaf(s[r], c2, -l4[r]));
+                            const bool keep = (keep4 >> r) & 1u;
+                            pd[r] = keep ? p * ks : 0.f;
+                            ds[r] = p * ((keep ? dpd[r] * kss : 0.f) - d4[r]);
+                        }
+                        pk[c][2 * half] = pack_bf16(pd[0], pd[1]);
+                        pk[c][2 * half + 1] = pack_bf16(pd[2], pd[3]);
+                        dsk[c][2 * half] = pack_bf16(ds[0], ds[1]);
+                        dsk[c][2 * half + 1] = pack_bf16(ds[2], ds[3]);
+                        *reinterpret_cast<u32x2 *>(Tw + (16 * c + j) * 16 + 4 * g) = u32x2{dsk[c][2 * half], dsk[c][2 * half + 1]};
+                        __builtin_amdgcn_sched_barrier(0);     // one tile at a time (register pressure: the loops are fully unrolled)
+                    }
+                asm volatile("" ::: "memory");      // the tile stores stay in front of the transposing reads (same wave: in order)
+                // dQ^T[d][query of tile qt] += K^T[d][this wave's keys] dS^T
+#pragma unroll
+                for (int uu = 0; uu < KPW / 2; ++uu)
+                    if (FULL || w * KPW + 2 * uu < KT)
+                        dq[qt] = mfma_bf16(col_frag(KTi, ldt, 0, (w * KPW) / 2 + uu, lane), tr_frag_bf16(Tlane, 32 * uu), dq[qt]);
+                asm volatile("" ::: "memory");      // ... and in front of the next tile's stores
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int c = 0; c < KPW; ++c) {
+                    const u32x4 pf = {pk[c][0], pk[c][1], pk[c][2], pk[c][3]}, dsf = {dsk[c][0], dsk[c][1], dsk[c][2], dsk[c][3]};
+                    dv[c] = mfma_bf16(col_frag(dOT, ldt, 0, u2, lane), pf, dv[c]);
+                    dkk[c] = mfma_bf16(col_frag(QT, ldt, 0, u2, lane), dsf, dkk[c]);
+                }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+    for (int c = 0; c < KPW; ++c) {
+        const int key = 16 * (w * KPW + c) + j;
+        if ((FULL || w * KPW + c < KT) && key < a.S) {
+            bf16_t *row = a.out + ((long long)b * a.S + key) * 3 * d + hd * a.dk;
+            store4(row + d, 4 * g, a.dk, a.dk % 4 == 0, dkk[c]);
+            store4(row + 2 * d, 4 * g, a.dk, a.dk % 4 == 0, dv[c]);
+        }
+    }
+    // dQ: the four waves' partials (disjoint key ranges) summed in wave order through LDS (the image memory, now free)
+    __syncthreads();
+    float *R = reinterpret_cast<float *>(smem);                                    // [4][Sp][16]
+#pragma unroll
+    for (int qt = 0; qt < KTMAX; ++qt)
+        if (qt < KT) *reinterpret_cast<f32x4 *>(R + ((size_t)w * Sp + 16 * qt + j) * 16 + 4 * g) = dq[qt];
+    __syncthreads();
+    for (int e = threadIdx.x; e < Sp * 4; e += kAttThreads) {
+        const int q = e >> 2, ch = e & 3;
+        if (q >= a.S) continue;
+        f32x4 v = *reinterpret_cast<const f32x4 *>(R + (size_t)q * 16 + 4 * ch);
+#pragma unroll
+        for (int ww = 1; ww < 4; ++ww) v += *reinterpret_cast<const f32x4 *>(R + ((size_t)ww * Sp + q) * 16 + 4 * ch);
+        store4(a.out + ((long long)b * a.S + q) * 3 * d + hd * a.dk, 4 * ch, a.dk, a.dk % 4 == 0, v);
+    }
+}
+
+inline size_t att_bwd_km_lds(int S) {
+    const int Sp = round_up(S, 32), KPW = (Sp <= 128 ? 8 : 16) / 4;
+    return (size_t)(2 * Sp * kRowLd + 3 * 16 * tr_ld(Sp) + 4 * 16 * KPW * 16) * sizeof(bf16_t) + (size_t)Sp * 12;
+}
+
 // p_attn of transformer.py:161-163 as a tensor (what `attention()` RETURNS next to its output; nothing on the training path
 // reads it): probs [B][h][S][S] fp32 = dropout(softmax(q k^T / sqrt(dk) + mask)), the same numbers attention_fwd_kernel
 // feeds into P.V before its bf16 rounding.  One wave per (slate-head, query); lanes over keys.  Not a hot kernel.
@@ -1958,6 +2124,27 @@ int launch_att_tagged(const AttArgs &a, size_t lds, hipStream_t stream) {
     }
     hipLaunchKernelGGL(kernel, dim3(att_grid(a.B, a.h)), dim3(kAttThreads), lds, stream, a);
     return status();
+}
+template <int KTMAX, bool FULL>
+int launch_att_km(const AttArgs &a, hipStream_t stream) {
+    static bool done[64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = -1;
+    auto kernel = attention_bwd_km_kernel<KTMAX, FULL>;
+    if (dev < 0 || !done[dev]) {
+        hipError_t e = hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return (int)e;
+        if (dev >= 0) done[dev] = true;
+    }
+    hipLaunchKernelGGL(kernel, dim3(att_grid(a.B, a.h)), dim3(kAttThreads), att_bwd_km_lds(a.S), stream, a);
+    return status();
+}
+// the one-pass key-major backward: head dimension within one 16-row image, slate within 16 key tiles, lse2 saved
+inline bool att_km_ok(const AttArgs &a) { return a.lse != nullptr && a.dk <= 16 && a.S <= 256; }
+int dispatch_att_km(const AttArgs &a, hipStream_t stream) {
+    const int Sp = round_up(a.S, 32);
+    if (Sp <= 128) return Sp == 128 ? launch_att_km<8, true>(a, stream) : launch_att_km<8, false>(a, stream);
+    return Sp == 256 ? launch_att_km<16, true>(a, stream) : launch_att_km<16, false>(a, stream);
 }
 template <bool BWD>
 int dispatch_att(const AttArgs &a, size_t lds, hipStream_t stream) {
@@ -2137,29 +2324,38 @@ int ltr_enc_drop_cast_colsum(const float *dx, int64_t T, int N, float p, uint64_
     return status();
 }
 
-int ltr_enc_attention_fwd(const uint16_t *qkv, const uint8_t *mask, int B, int S, int h, int dk, float drop_p,
-                          uint64_t seed, int stream_id, uint16_t *ctx, void *stream) {
+int ltr_enc_attention_fwd_lse(const uint16_t *qkv, const uint8_t *mask, int B, int S, int h, int dk, float drop_p,
+                              uint64_t seed, int stream_id, uint16_t *ctx, float *lse, void *stream) {
     if (int rc = check_att(qkv, ctx, B, S, h, dk, drop_p)) return rc;
     if (B == 0) return LTR_OK;
-    AttArgs a{qkv, nullptr, nullptr, mask, ctx, B, S, h, dk, drop_p, (unsigned long long)seed, stream_id};
+    AttArgs a{qkv, nullptr, nullptr, mask, ctx, B, S, h, dk, drop_p, (unsigned long long)seed, stream_id, lse};
     return dispatch_att<false>(a, att_fwd_lds(S), (hipStream_t)stream);
 }
+int ltr_enc_attention_fwd(const uint16_t *qkv, const uint8_t *mask, int B, int S, int h, int dk, float drop_p,
+                          uint64_t seed, int stream_id, uint16_t *ctx, void *stream) {
+    return ltr_enc_attention_fwd_lse(qkv, mask, B, S, h, dk, drop_p, seed, stream_id, ctx, nullptr, stream);
+}
 
-int ltr_enc_attention_bwd(const uint16_t *qkv, const uint16_t *ctx, const uint16_t *dctx, const uint8_t *mask, int B, int S, int h,
-                          int dk, float drop_p, uint64_t seed, int stream_id, uint16_t *dqkv, void *stream) {
+int ltr_enc_attention_bwd_lse(const uint16_t *qkv, const uint16_t *ctx, const uint16_t *dctx, const float *lse, const uint8_t *mask,
+                              int B, int S, int h, int dk, float drop_p, uint64_t seed, int stream_id, uint16_t *dqkv, void *stream) {
     if (!dctx || !ctx) return LTR_ERR_NULL;
     if (int rc = check_att(qkv, dqkv, B, S, h, dk, drop_p)) return rc;
     if (((uintptr_t)dctx & 15u) || ((uintptr_t)ctx & 15u)) return LTR_ERR_ALIGN;
     if (B == 0) return LTR_OK;
-    AttArgs a{qkv, dctx, ctx, mask, dqkv, B, S, h, dk, drop_p, (unsigned long long)seed, stream_id};
+    AttArgs a{qkv, dctx, ctx, mask, dqkv, B, S, h, dk, drop_p, (unsigned long long)seed, stream_id, const_cast<float *>(lse)};
+    if (att_km_ok(a)) return dispatch_att_km(a, (hipStream_t)stream);
     return dispatch_att<true>(a, att_bwd_lds(S), (hipStream_t)stream);
+}
+int ltr_enc_attention_bwd(const uint16_t *qkv, const uint16_t *ctx, const uint16_t *dctx, const uint8_t *mask, int B, int S, int h,
+                          int dk, float drop_p, uint64_t seed, int stream_id, uint16_t *dqkv, void *stream) {
+    return ltr_enc_attention_bwd_lse(qkv, ctx, dctx, nullptr, mask, B, S, h, dk, drop_p, seed, stream_id, dqkv, stream);
 }
 
 int ltr_enc_attention_probs(const uint16_t *qkv, const uint8_t *mask, int B, int S, int h, int dk, float drop_p, uint64_t seed,
                             int stream_id, float *probs, void *stream) {
     if (int rc = check_att(qkv, probs, B, S, h, dk, drop_p)) return rc;
     if (B == 0) return LTR_OK;
-    AttArgs a{qkv, nullptr, nullptr, mask, nullptr, B, S, h, dk, drop_p, (unsigned long long)seed, stream_id};
+    AttArgs a{qkv, nullptr, nullptr, mask, nullptr, B, S, h, dk, drop_p, (unsigned long long)seed, stream_id, nullptr};
     const long long rows = (long long)B * h * S;
     hipLaunchKernelGGL(attn_probs_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, a, probs);
     return status();

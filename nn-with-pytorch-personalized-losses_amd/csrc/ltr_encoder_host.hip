@@ -39,6 +39,7 @@ struct LayerBuf {
     const float *x0;                 // residual stream into the block (the previous block's x2 / the FC output)
     uint16_t *n1, *qkv, *ctx, *n2, *hid;
     float *x1, *x2, *bqkv;
+    float *lse;                      // [B*h][S] attention row statistic, forward -> backward
     uint16_t *wqkv, *wo, *w1, *w2;
     // backward temporaries
     uint16_t *dy2, *dz1, *dyo, *dctx, *dqkv;
@@ -121,6 +122,7 @@ void make_layout(const ltr_enc_spec &sp, int B, int S, void *base, Layout &Y) {
         l.n1 = ws.take<uint16_t>(T * d);
         l.qkv = ws.take<uint16_t>(T * 3 * d);
         l.ctx = ws.take<uint16_t>(T * d);
+        l.lse = ws.take<float>(T * (size_t)Y.h);
         l.x1 = ws.take<float>(T * d);
         l.n2 = ws.take<uint16_t>(T * d);
         l.hid = Y.fused ? nullptr : ws.take<uint16_t>(T * dff);
@@ -249,7 +251,7 @@ int ltr_enc_forward(const ltr_enc_spec *spec, const float *x, const uint8_t *mas
         b.x0 = stream_x;
         TRY(ltr_enc_layernorm_fwd(b.x0, P[0], P[1], T, (int)d, kLnEps, 0, b.n1, nullptr, stream));
         TRY(gemm(b.n1, b.wqkv, T, 3 * d, d, false, false, nullptr, b.qkv, b.bqkv, nullptr, nullptr, 1.f, 0, 0.f, 0, 0, 1, stream));
-        TRY(ltr_enc_attention_fwd(b.qkv, mask, B, S, Y.h, Y.dk, p_enc, seed, stream_attn(l), b.ctx, stream));
+        TRY(ltr_enc_attention_fwd_lse(b.qkv, mask, B, S, Y.h, Y.dk, p_enc, seed, stream_attn(l), b.ctx, b.lse, stream));
         TRY(gemm(b.ctx, b.wo, T, d, d, false, false, b.x1, nullptr, P[9], b.x0, nullptr, 1.f, 0, p_enc, seed, stream_attn_out(l), 1, stream));
         TRY(ltr_enc_layernorm_fwd(b.x1, P[10], P[11], T, (int)d, kLnEps, 0, b.n2, nullptr, stream));
         if (Y.fused)
@@ -331,7 +333,7 @@ int ltr_enc_backward(const ltr_enc_spec *spec, const float *x, const uint8_t *ma
         TRY(gemm(b.dyo, b.ctx, d, d, T, true, true, b.p_wo, nullptr, nullptr, nullptr, nullptr, 1.f, 0, 0.f, 0, 0, b.s_wo, stream));
         reduce(b.p_wo, b.s_wo, d * d, G[8]);
         TRY(gemm(b.dyo, b.wo, T, d, d, false, true, nullptr, b.dctx, nullptr, nullptr, nullptr, 1.f, 0, 0.f, 0, 0, 1, stream));
-        TRY(ltr_enc_attention_bwd(b.qkv, b.ctx, b.dctx, mask, B, S, Y.h, Y.dk, p_enc, seed, stream_attn(l), b.dqkv, stream));
+        TRY(ltr_enc_attention_bwd_lse(b.qkv, b.ctx, b.dctx, b.lse, mask, B, S, Y.h, Y.dk, p_enc, seed, stream_attn(l), b.dqkv, stream));
         TRY(ltr_enc_colsum_bf16(b.dqkv, T, (int)(3 * d), b.p_bqkv, Y.nblk_rows, stream));
         TRY(gemm(b.dqkv, b.n1, 3 * d, d, T, true, true, b.p_wqkv, nullptr, nullptr, nullptr, nullptr, 1.f, 0, 0.f, 0, 0, b.s_wqkv, stream));
         for (int j = 0; j < 3; ++j) {

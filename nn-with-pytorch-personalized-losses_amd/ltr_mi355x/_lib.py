@@ -55,6 +55,8 @@ _PROTOTYPES = {
     "ltr_enc_drop_cast_colsum": (c_int, [P, c_int64, c_int, c_float, c_uint64, c_int, P, P, c_int, P]),
     "ltr_enc_attention_fwd": (c_int, [P, P, c_int, c_int, c_int, c_int, c_float, c_uint64, c_int, P, P]),
     "ltr_enc_attention_bwd": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_float, c_uint64, c_int, P, P]),
+    "ltr_enc_attention_fwd_lse": (c_int, [P, P, c_int, c_int, c_int, c_int, c_float, c_uint64, c_int, P, P, P]),
+    "ltr_enc_attention_bwd_lse": (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, c_float, c_uint64, c_int, P, P]),
     "ltr_enc_attention_probs": (c_int, [P, P, c_int, c_int, c_int, c_int, c_float, c_uint64, c_int, P, P]),
     "ltr_enc_ffn_supported": (c_int, [c_int, c_int]),
     "ltr_enc_ffn_fwd": (c_int, [P, P, P, P, P, P, c_int64, c_int, c_int, c_float, c_uint64, c_int, c_int, P, P]),

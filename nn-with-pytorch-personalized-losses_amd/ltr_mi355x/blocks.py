@@ -271,12 +271,10 @@ class MultiHeadFn(torch.autograd.Function):
             else:
                 for j in range(3):
                     E.gemm(srcs[j], wqkv[j * d:(j + 1) * d], T, d, d, Cb=qkv[:, j * d:], ldc=3 * d, bias=bqkv[j * d:(j + 1) * d])
-            ctxb = torch.empty((T, d), dtype=_U16, device=dev)
-            check(lib().ltr_enc_attention_fwd(_ptr(qkv), _ptr(mask_u8), B, S, h, dk, float(p), int(seed), 0, _ptr(ctxb), _stream()),
-                  "ltr_enc_attention_fwd")
+            ctxb, lse = E.attention_fwd(qkv, mask_u8, B, S, h, dk, p, seed, 0)
             out = torch.empty((T, d), dtype=torch.float32, device=dev)
             E.gemm(ctxb, wo16, T, d, d, Cf=out, bias=_f32(bo))
-        ctx.saved = (srcs, wqkv, wo16, qkv, ctxb, mask_u8)
+        ctx.saved = (srcs, wqkv, wo16, qkv, ctxb, mask_u8, lse)
         return out.view(B, S, d)
 
     @staticmethod
@@ -288,7 +286,7 @@ class MultiHeadFn(torch.autograd.Function):
             gp = [z(d, d), z(d)] * 4
             return (None, None, None, None, z(B, S, d), None if same else z(B, S, d), None if same else z(B, S, d), None,
                     *[g.to(t) for g, t in zip(gp, p_dts)])
-        srcs, wqkv, wo16, qkv, ctxb, mask_u8 = ctx.saved
+        srcs, wqkv, wo16, qkv, ctxb, mask_u8, lse = ctx.saved
         T, dk = B * S, d // h
         with torch.cuda.device(dev):
             g = dout.detach().to(torch.float32).contiguous().view(T, d)
@@ -296,9 +294,7 @@ class MultiHeadFn(torch.autograd.Function):
             gWo = E._weight_grad(dy16, ctxb, T, d, d)
             dctx = torch.empty((T, d), dtype=_U16, device=dev)
             E.gemm(dy16, wo16, T, d, d, b_kmajor=True, Cb=dctx)
-            dqkv = torch.empty((T, 3 * d), dtype=_U16, device=dev)
-            check(lib().ltr_enc_attention_bwd(_ptr(qkv), _ptr(ctxb), _ptr(dctx), _ptr(mask_u8), B, S, h, dk, p, seed, 0, _ptr(dqkv),
-                                              _stream()), "ltr_enc_attention_bwd")
+            dqkv = E.attention_bwd(qkv, ctxb, dctx, lse, mask_u8, B, S, h, dk, p, seed, 0)
             gbqkv = E._colsum(dqkv, T, 3 * d)
             need = ctx.needs_input_grad[4:7]
             if same:
@@ -339,22 +335,18 @@ class AttentionCoreFn(torch.autograd.Function):
         with torch.cuda.device(dev):
             packed = torch.cat([t.detach().to(torch.float32).transpose(1, 2).reshape(T, d) for t in (query, key, value)], 1).contiguous()
             qkv = E.cast_bf16(packed)
-            ctxb = torch.empty((T, d), dtype=_U16, device=dev)
-            check(lib().ltr_enc_attention_fwd(_ptr(qkv), _ptr(mask_u8), B, S, h, dk, float(p), int(seed), 0, _ptr(ctxb), _stream()),
-                  "ltr_enc_attention_fwd")
-        ctx.saved = (qkv, ctxb, mask_u8)
+            ctxb, lse = E.attention_fwd(qkv, mask_u8, B, S, h, dk, p, seed, 0)
+        ctx.saved = (qkv, ctxb, mask_u8, lse)
         return ctxb.view(torch.bfloat16).to(torch.float32).view(B, S, h, dk).transpose(1, 2).contiguous()
 
     @staticmethod
     def backward(ctx, dout):
         B, h, S, dk, p, seed, dts = ctx.meta
-        qkv, ctxb, mask_u8 = ctx.saved
+        qkv, ctxb, mask_u8, lse = ctx.saved
         d, T, dev = h * dk, B * S, dout.device
         with torch.cuda.device(dev):
             dctx = E.cast_bf16(dout.detach().to(torch.float32).transpose(1, 2).reshape(T, d))
-            dqkv = torch.empty((T, 3 * d), dtype=_U16, device=dev)
-            check(lib().ltr_enc_attention_bwd(_ptr(qkv), _ptr(ctxb), _ptr(dctx), _ptr(mask_u8), B, S, h, dk, p, seed, 0, _ptr(dqkv),
-                                              _stream()), "ltr_enc_attention_bwd")
+            dqkv = E.attention_bwd(qkv, ctxb, dctx, lse, mask_u8, B, S, h, dk, p, seed, 0)
             g = dqkv.view(torch.bfloat16).to(torch.float32).view(B, S, 3, h, dk).permute(2, 0, 3, 1, 4)
         return g[0].to(dts[0]), g[1].to(dts[1]), g[2].to(dts[2]), None, None, None
 

@@ -169,6 +169,24 @@ def layernorm_bwd(x, a, dy, T, d, eps, standard, dx):
     return g[:d], g[d:]
 
 
+def attention_fwd(qkv, mask_u8, B, S, h, dk, p, seed, stream_id):
+    """ctx [T][d] bf16 and lse2 [B*h][S] fp32 (log2-sum-exp of the scaled scores; lets the backward evaluate every
+    probability once, key-major: csrc/ltr_encoder.hip attention_bwd_km_kernel)."""
+    T, d = B * S, h * dk
+    ctxb = torch.empty((T, d), dtype=_U16, device=qkv.device)
+    lse = torch.empty((B * h, S), dtype=torch.float32, device=qkv.device)
+    check(lib().ltr_enc_attention_fwd_lse(_ptr(qkv), _ptr(mask_u8), B, S, h, dk, float(p), int(seed), int(stream_id), _ptr(ctxb),
+                                          _ptr(lse), _stream()), "ltr_enc_attention_fwd_lse")
+    return ctxb, lse
+
+
+def attention_bwd(qkv, ctxb, dctx, lse, mask_u8, B, S, h, dk, p, seed, stream_id):
+    dqkv = torch.empty((B * S, 3 * h * dk), dtype=_U16, device=qkv.device)
+    check(lib().ltr_enc_attention_bwd_lse(_ptr(qkv), _ptr(ctxb), _ptr(dctx), _ptr(lse), _ptr(mask_u8), B, S, h, dk, float(p), int(seed),
+                                          int(stream_id), _ptr(dqkv), _stream()), "ltr_enc_attention_bwd_lse")
+    return dqkv
+
+
 def fused_ffn_enabled(d, dff):
     """The fused FFN kernels (no [T, d_ff] tensor in HBM) cover d_model in {64, 128} with d_ff a multiple of 128;
     LTR_ENC_FUSED_FFN=0 forces the GEMM path (A/B measurements, tests)."""
@@ -311,9 +329,7 @@ def _run_forward(spec, x, mask, seed, training, params):
             n1 = layernorm_fwd(x0, a1, b1n, T, d, LN_EPS, 0)
             qkv = torch.empty((T, 3 * d), dtype=_U16, device=dev)
             gemm(n1, wqkv, T, 3 * d, d, Cb=qkv, bias=bqkv)
-            ctxb = torch.empty((T, d), dtype=_U16, device=dev)
-            check(lib().ltr_enc_attention_fwd(_ptr(qkv), _ptr(mask_u8), B, S, h, dk, p_enc, int(seed), stream_attn(l),
-                                              _ptr(ctxb), _stream()), "ltr_enc_attention_fwd")
+            ctxb, lse = attention_fwd(qkv, mask_u8, B, S, h, dk, p_enc, seed, stream_attn(l))
             x1 = torch.empty((T, d), dtype=torch.float32, device=dev)
             gemm(ctxb, wo16, T, d, d, Cf=x1, bias=bo, residual=x0, drop_p=p_enc, seed=seed, drop_stream=stream_attn_out(l))
             n2 = layernorm_fwd(x1, a2, b2n, T, d, LN_EPS, 0)
@@ -325,7 +341,7 @@ def _run_forward(spec, x, mask, seed, training, params):
                 gemm(n2, w116, T, dff, d, Cb=hid, bias=b1, relu=True, drop_p=p_enc, seed=seed, drop_stream=stream_ffn_hidden(l))
                 x2 = torch.empty((T, d), dtype=torch.float32, device=dev)
                 gemm(hid, w216, T, d, dff, Cf=x2, bias=b2, residual=x1, drop_p=p_enc, seed=seed, drop_stream=stream_ffn_out(l))
-            st["layers"].append((x0, n1, qkv, ctxb, x1, n2, hid))
+            st["layers"].append((x0, n1, qkv, ctxb, x1, n2, hid, lse))
             stream_x = x2
     st["xin"], st["prm"], st["final_x"] = xin, prm, stream_x
     return st
@@ -409,7 +425,7 @@ def _body_backward(spec, seed, st, dx, want_dx=False):
             base = n_fc + 16 * l
             a1, _, Wq, _, _, _, _, _, Wo, _, a2, _, W1, _, W2, _ = prm[base:base + 16]
             wqkv, wo16, w116, w216 = enc_w16[l]
-            x0, n1, qkv, ctxb, x1, n2, hid = st["layers"][l]
+            x0, n1, qkv, ctxb, x1, n2, hid, lse = st["layers"][l]
             # FFN sublayer: x2 = x1 + drop(hid W2^T + b2)
             dy2, gb2 = _drop_cast_colsum(dx, T, d, p_enc, seed, stream_ffn_out(l))
             if st["fused_ffn"]:
@@ -428,9 +444,7 @@ def _body_backward(spec, seed, st, dx, want_dx=False):
             gWo = _weight_grad(dyo, ctxb, T, d, d)
             dctx = torch.empty((T, d), dtype=_U16, device=dev)
             gemm(dyo, wo16, T, d, d, b_kmajor=True, Cb=dctx)
-            dqkv = torch.empty((T, 3 * d), dtype=_U16, device=dev)
-            check(lib().ltr_enc_attention_bwd(_ptr(qkv), _ptr(ctxb), _ptr(dctx), _ptr(st["mask_u8"]), B, S, h, dk, p_enc, int(seed),
-                                              stream_attn(l), _ptr(dqkv), _stream()), "ltr_enc_attention_bwd")
+            dqkv = attention_bwd(qkv, ctxb, dctx, lse, st["mask_u8"], B, S, h, dk, p_enc, seed, stream_attn(l))
             gbqkv = _colsum(dqkv, T, 3 * d)
             gWqkv = _weight_grad(dqkv, n1, T, 3 * d, d)
             dn1 = torch.empty((T, d), dtype=torch.float32, device=dev)

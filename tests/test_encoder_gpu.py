@@ -246,6 +246,63 @@ def test_attention_fwd_bwd(enc, B, S, h, dk, p):
         assert e < 1.5e-2, f"d{name}: {e}"
 
 
+@pytest.mark.parametrize("B,S,h,dk,p", [(2, 12, 4, 8, 0.0), (3, 40, 2, 16, 0.1), (2, 100, 8, 16, 0.1), (9, 128, 8, 16, 0.1), (2, 200, 4, 12, 0.0),
+                                        (2, 256, 8, 16, 0.2), (10, 256, 8, 16, 0.1), (3, 250, 8, 16, 0.0)])
+def test_attention_key_major_backward(enc, B, S, h, dk, p):
+    """ltr_enc_attention_fwd_lse / _bwd_lse (every probability evaluated once, key-major; dk <= 16, S <= 256): against the
+    fp64 reference at the bf16 bar of test_attention_fwd_bwd, against the two-phase kernel on the same inputs (same rounding
+    points; the only difference is exp2(c2 s - lse2) for exp2(c2 s - max) / sum in the dQ contraction), bit-reproducible,
+    and lse2 itself against log2-sum-exp of the reference scores."""
+    from ltr_mi355x._lib import check, lib
+    from ltr_mi355x.functional import _ptr, _stream
+    torch.manual_seed(S * h + dk + B)
+    d, T, seed, sid = h * dk, B * S, 99, 8
+    qkv = rnd(T, 3 * d, scale=1.5)
+    mask = torch.zeros(B, S, dtype=torch.uint8, device=DEV)
+    mask[0, S - S // 4:] = 1
+    if B > 2:
+        mask[2] = 1                              # a slate without any unmasked document: zeros, lse2 = +inf
+    qkv16, ctx, ctx0 = bits(qkv), torch.empty(T, d, dtype=torch.int16, device=DEV), torch.empty(T, d, dtype=torch.int16, device=DEV)
+    lse = torch.full((B * h, S), float("nan"), device=DEV)
+    check(lib().ltr_enc_attention_fwd_lse(_ptr(qkv16), _ptr(mask), B, S, h, dk, p, seed, sid, _ptr(ctx), _ptr(lse), _stream()), "fwd")
+    check(lib().ltr_enc_attention_fwd(_ptr(qkv16), _ptr(mask), B, S, h, dk, p, seed, sid, _ptr(ctx0), _stream()), "fwd")
+    assert torch.equal(ctx, ctx0)
+    q, k, v = (unbits(qkv16)[:, j * d:(j + 1) * d].double().view(B, S, h, dk).transpose(1, 2) for j in range(3))
+    sc = (q @ k.transpose(-2, -1) / math.sqrt(dk)).masked_fill((mask == 1).view(B, 1, 1, S), float("-inf"))
+    want_lse = torch.logsumexp(sc, -1) / math.log(2.0)
+    live = torch.isfinite(want_lse)
+    got_lse = lse.view(B, h, S).double()
+    assert torch.all(torch.isinf(got_lse[~live]) & (got_lse[~live] > 0))
+    assert float((got_lse[live] - want_lse[live]).abs().max()) < 2e-5 * max(1.0, float(want_lse[live].abs().max()))
+    dctx16 = bits(rnd(T, d))
+    out = [torch.empty(T, 3 * d, dtype=torch.int16, device=DEV) for _ in range(3)]
+    for o in out[:2]:
+        check(lib().ltr_enc_attention_bwd_lse(_ptr(qkv16), _ptr(ctx), _ptr(dctx16), _ptr(lse), _ptr(mask), B, S, h, dk, p, seed, sid,
+                                              _ptr(o), _stream()), "bwd_lse")
+    check(lib().ltr_enc_attention_bwd(_ptr(qkv16), _ptr(ctx), _ptr(dctx16), _ptr(mask), B, S, h, dk, p, seed, sid, _ptr(out[2]),
+                                      _stream()), "bwd")
+    assert torch.equal(out[0], out[1])
+    km, two = unbits(out[0]), unbits(out[2])
+    for j, name in enumerate("qkv"):
+        e = err(km[:, j * d:(j + 1) * d], two[:, j * d:(j + 1) * d])
+        assert e < 8e-3, f"d{name} vs the two-phase kernel: {e}"           # one bf16 ulp of the largest entry = 3.9e-3
+    # fp64 reference through autograd, dropout keep mask exported from the same stream
+    keep = enc.attn_dropout_mask(seed, sid, B, S, h, p, DEV).double() if p else None
+    qr = unbits(qkv16).double().clone().requires_grad_(True)
+    q, k, v = (qr[:, j * d:(j + 1) * d].view(B, S, h, dk).transpose(1, 2) for j in range(3))
+    okb = [b for b in range(B) if not bool((mask[b] == 1).all())]      # the reference yields NaN for an all-masked slate
+    want = _attention_ref(q[okb], k[okb], v[okb], (mask[okb] == 1).view(len(okb), 1, 1, S), None if keep is None else keep[okb], p, dk)
+    want = want.transpose(1, 2).reshape(len(okb) * S, d)
+    rows = torch.cat([torch.arange(b * S, (b + 1) * S, device=DEV) for b in okb])
+    want.backward(unbits(dctx16)[rows].double())
+    for j, name in enumerate("qkv"):
+        e = err(km[rows, j * d:(j + 1) * d], qr.grad[rows, j * d:(j + 1) * d])
+        assert e < 1.5e-2, f"d{name}: {e}"
+    dead = [b for b in range(B) if b not in okb]
+    for b in dead:
+        assert float(km[b * S:(b + 1) * S].abs().max()) == 0.0
+
+
 def test_attention_without_mask_and_all_masked_slate(enc):
     from ltr_mi355x._lib import check, lib
     from ltr_mi355x.functional import _ptr, _stream

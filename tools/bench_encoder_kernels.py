@@ -82,6 +82,12 @@ def main():
                                                                                        _stream()), "f")), att_f, T * d * 8)
         rec(f"attention bwd p={p}", timeit(lambda: check(lib().ltr_enc_attention_bwd(_ptr(qkv), _ptr(ctx), _ptr(dy), _ptr(mask), B, S, h, dk, p, 1, 0,
                                                                                        _ptr(dqkv), _stream()), "b")), att_f * 3.5, T * d * 16)
+    lse = torch.empty(B * h, S, device=dev)
+    for p in (0.0, 0.1):
+        rec(f"attention fwd +lse p={p}", timeit(lambda: check(lib().ltr_enc_attention_fwd_lse(_ptr(qkv), _ptr(mask), B, S, h, dk, p, 1, 0, _ptr(ctx),
+                                                                                                _ptr(lse), _stream()), "f")), att_f, T * d * 8)
+        rec(f"attention bwd key-major (lse) p={p}", timeit(lambda: check(lib().ltr_enc_attention_bwd_lse(
+            _ptr(qkv), _ptr(ctx), _ptr(dy), _ptr(lse), _ptr(mask), B, S, h, dk, p, 1, 0, _ptr(dqkv), _stream()), "b")), att_f * 2.5, T * d * 16)
     xf, a_, b_ = torch.randn(T, d, device=dev), torch.ones(d, device=dev), torch.zeros(d, device=dev)
     rec("layernorm fwd (-> bf16)", timeit(lambda: E.layernorm_fwd(xf, a_, b_, T, d, 1e-6, 0)), 0, T * d * 6)
     dxa = torch.zeros(T, d, device=dev)
