@@ -50,45 +50,51 @@ __device__ __forceinline__ unsigned mix32(unsigned h) {
     h ^= h >> 16; h *= 0x85EBCA6Bu; h ^= h >> 13; h *= 0xC2B2AE35u; h ^= h >> 16;
     return h;
 }
-// 32 hash bits shared by elements 2*pair and 2*pair + 1 of stream `stream_id`: one murmur3 finaliser over the pair
-// counter xor a per-(seed, stream) key.  The key is wave-uniform (hoisted out of every loop by the compiler); per
-// element pair this costs two 32-bit multiplies.
+// 32 hash bits shared by the FOUR elements 4*quad .. 4*quad + 3 of stream `stream_id`: one murmur3 finaliser over the quad
+// counter xor a per-(seed, stream) key (wave-uniform, hoisted out of every loop by the compiler).  Element r of the quad
+// is kept when the 16-bit window of the word starting at byte r (low byte r, high byte r+1 mod 4: each byte is the HIGH byte
+// of one element and the tie-break LOW byte of its neighbour) is >= the threshold p * 65536: every element's window is an
+// exactly uniform 16-bit number (two distinct bytes of a uniform word), so the keep probability is exactly
+// 1 - thr / 65536, and a neighbour's byte decides an element only in the 1 / 256 of cases where its own high byte ties
+// the threshold's.  Half the multiplies per element of one word per pair (the hash is ~20 % of the fused-FFN and ~25 %
+// of the attention kernels' time at p > 0); the statistics are tested in tests/test_encoder_gpu.py.
 __device__ __forceinline__ unsigned drop_key(unsigned long long seed, int stream_id) {
     return mix32((unsigned)seed ^ (0x9E3779B9u * (unsigned)(stream_id + 1))) ^ mix32((unsigned)(seed >> 32) + 0x85EBCA6Bu * (unsigned)stream_id);
 }
-__device__ __forceinline__ unsigned drop_word(unsigned long long seed, int stream_id, unsigned long long pair) {
-    return mix32((unsigned)pair ^ drop_key(seed, stream_id) ^ (0x27D4EB2Fu * (unsigned)(pair >> 32)));
+__device__ __forceinline__ unsigned drop_word(unsigned long long seed, int stream_id, unsigned long long quad) {
+    return mix32((unsigned)quad ^ drop_key(seed, stream_id) ^ (0x27D4EB2Fu * (unsigned)(quad >> 32)));
 }
 __host__ __device__ inline unsigned drop_threshold(float p) {
     if (!(p > 0.f)) return 0u;
     unsigned t = (unsigned)(p * 65536.f + 0.5f);
     return t > 65535u ? 65535u : t;
 }
+// the 16-bit window of element r (0..3) of a quad's word
+__device__ __forceinline__ unsigned drop_win(unsigned w, unsigned r) { return __builtin_amdgcn_alignbit(w, w, 8u * r) & 0xffffu; }
 __device__ __forceinline__ bool drop_keep(unsigned long long seed, int stream_id, unsigned long long idx, unsigned thr) {
-    const unsigned w = drop_word(seed, stream_id, idx >> 1);
-    return ((w >> (16 * (unsigned)(idx & 1))) & 0xffffu) >= thr;
+    return drop_win(drop_word(seed, stream_id, idx >> 2), (unsigned)(idx & 3)) >= thr;
 }
-// keep flags of 4 consecutive elements idx .. idx+3, idx even: bit r = element idx + r
+// keep flags of 4 consecutive elements idx .. idx+3, idx a multiple of 4: bit r = element idx + r
 __device__ __forceinline__ unsigned drop_keep4(unsigned long long seed, int stream_id, unsigned long long idx, unsigned thr) {
-    const unsigned w0 = drop_word(seed, stream_id, idx >> 1), w1 = drop_word(seed, stream_id, (idx >> 1) + 1);
-    return ((w0 & 0xffffu) >= thr ? 1u : 0u) | ((w0 >> 16) >= thr ? 2u : 0u) | ((w1 & 0xffffu) >= thr ? 4u : 0u) |
-           ((w1 >> 16) >= thr ? 8u : 0u);
+    const unsigned w = drop_word(seed, stream_id, idx >> 2);
+    return (drop_win(w, 0) >= thr ? 1u : 0u) | (drop_win(w, 1) >= thr ? 2u : 0u) | (drop_win(w, 2) >= thr ? 4u : 0u) |
+           (drop_win(w, 3) >= thr ? 8u : 0u);
 }
 
-// keep flags of 4 elements in ONE column over 4 consecutive rows (idx0 + r * row_stride, r = 0..3) when adjacent lanes
-// hold adjacent columns (even lane = even idx0, row_stride even): the hash word of a row is shared by the lane pair, so
-// each lane evaluates two rows and takes the other two from its partner with one DPP quad-perm each.  EXEC must be full.
+// keep flags of 4 elements in ONE column over 4 consecutive rows (idx0 + r * row_stride, r = 0..3) when the four lanes of an
+// aligned lane quad hold four adjacent columns of one element quad ((idx0 & 3) == (lane & 3), row_stride a multiple of 4):
+// the word of row r is the same for the whole lane quad, so lane i evaluates row i and takes the other three with one DPP
+// quad-perm broadcast each -- ONE hash per lane for its four elements.  EXEC must be full.
 __device__ __forceinline__ unsigned drop_keep_col4(unsigned long long seed, int stream_id, unsigned long long idx0,
                                                    unsigned long long row_stride, unsigned thr, int lane) {
-    const int par = lane & 1;
-    const unsigned long long base = (idx0 >> 1) + (unsigned long long)(2 * par) * (row_stride >> 1);   // pair index of row 2 par
-    const unsigned wa = drop_word(seed, stream_id, base), wb = drop_word(seed, stream_id, base + (row_stride >> 1));
-    const unsigned xa = (unsigned)__builtin_amdgcn_update_dpp(0, (int)wa, 0xB1, 0xF, 0xF, false);      // partner (lane ^ 1)
-    const unsigned xb = (unsigned)__builtin_amdgcn_update_dpp(0, (int)wb, 0xB1, 0xF, 0xF, false);
-    const unsigned w0 = par ? xa : wa, w1 = par ? xb : wb, w2 = par ? wa : xa, w3 = par ? wb : xb;
-    const unsigned sh = 16u * (unsigned)par;
-    return (((w0 >> sh) & 0xffffu) >= thr ? 1u : 0u) | (((w1 >> sh) & 0xffffu) >= thr ? 2u : 0u) |
-           (((w2 >> sh) & 0xffffu) >= thr ? 4u : 0u) | (((w3 >> sh) & 0xffffu) >= thr ? 8u : 0u);
+    const unsigned i = (unsigned)lane & 3u;
+    const unsigned mine = drop_word(seed, stream_id, (idx0 >> 2) + (unsigned long long)i * (row_stride >> 2));
+    const unsigned w0 = (unsigned)__builtin_amdgcn_update_dpp(0, (int)mine, 0x00, 0xF, 0xF, false);      // quad_perm [0,0,0,0]
+    const unsigned w1 = (unsigned)__builtin_amdgcn_update_dpp(0, (int)mine, 0x55, 0xF, 0xF, false);      // [1,1,1,1]
+    const unsigned w2 = (unsigned)__builtin_amdgcn_update_dpp(0, (int)mine, 0xAA, 0xF, 0xF, false);      // [2,2,2,2]
+    const unsigned w3 = (unsigned)__builtin_amdgcn_update_dpp(0, (int)mine, 0xFF, 0xF, 0xF, false);      // [3,3,3,3]
+    return (drop_win(w0, i) >= thr ? 1u : 0u) | (drop_win(w1, i) >= thr ? 2u : 0u) | (drop_win(w2, i) >= thr ? 4u : 0u) |
+           (drop_win(w3, i) >= thr ? 8u : 0u);
 }
 
 __global__ void dropout_mask_kernel(unsigned long long seed, int stream_id, long long n, unsigned thr, uint8_t *out) {

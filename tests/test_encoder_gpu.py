@@ -201,6 +201,33 @@ def test_score_tail_fwd_bwd(enc, norm):
         assert err(g[:d], ar.grad) < 2e-5 and err(g[d:2 * d], br.grad) < 2e-5
 
 
+# ------------------------------------------------------------------------------------------------- dropout stream
+@pytest.mark.parametrize("p", [0.1, 0.5, 0.0037])
+def test_dropout_stream_statistics(enc, p):
+    """One 32-bit hash word serves four elements through overlapping 16-bit windows (csrc/ltr_encoder.hip, dropout stream):
+    the keep rate must be exact to sampling error, and elements that SHARE a word (lags 1..3 inside a quad) as independent
+    as elements that do not (lag 4), within 5 sigma of 4 M samples; two streams / two seeds are uncorrelated."""
+    n = 1 << 22
+    m = enc.dropout_mask(1234, 3, n, p, DEV).double()
+    q = 1 - round(p * 65536) / 65536
+    sig = math.sqrt(q * (1 - q) / n)
+    assert abs(float(m.mean()) - q) < 5 * sig
+    quad = m.view(-1, 4)
+    for r in range(4):                                   # every position of the quad on its own
+        assert abs(float(quad[:, r].mean()) - q) < 5 * 2 * sig
+    var = q * (1 - q)
+    for lag in (1, 2, 3, 4, 5, 64):
+        c = float(((m[:-lag] - q) * (m[lag:] - q)).mean()) / var
+        assert abs(c) < 5 / math.sqrt(n), f"lag {lag}: {c}"
+    for a in range(4):                                   # pairs inside one quad (they share the hash word)
+        for b in range(a + 1, 4):
+            c = float(((quad[:, a] - q) * (quad[:, b] - q)).mean()) / var
+            assert abs(c) < 5 / math.sqrt(n / 4), f"quad positions {a},{b}: {c}"
+    for other in (enc.dropout_mask(1234, 4, n, p, DEV).double(), enc.dropout_mask(1235, 3, n, p, DEV).double()):
+        c = float(((m - q) * (other - q)).mean()) / var
+        assert abs(c) < 5 / math.sqrt(n)
+
+
 # ------------------------------------------------------------------------------------------------- attention
 def _attention_ref(q, k, v, pad, keep, p, dk):
     """transformer.py:145-164 on [B, h, S, dk] fp64 tensors; P rounded to bf16 after dropout like the kernel."""
