@@ -295,7 +295,8 @@ def main():
             "roofline": {"bound": "mfma", "achieved": round(ach_tf, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(ach_tf / PEAK_F32_MFMA_TFLOPS, 4),
                          "traffic": pmc_traffic_per_launch(a.net, B) if S == 128 else None,
-                         "kernel": "slate_pipeline_kernel<MODE_FUSED>" if one_launch else "whole step: pipeline<MODE_FWD> + loss kernel + pipeline<MODE_BWD>",
+                         "kernel": ("fcw_fused_kernel (feature-partitioned, csrc/ltr_fcw.h)" if a.net == "two64" else "slate_pipeline_kernel<MODE_FUSED>") if one_launch
+                         else "whole step: pipeline<MODE_FWD> + loss kernel + pipeline<MODE_BWD>",
                          "kernel_ms": round(kern_ms, 4),
                          "flops_per_slate": fl_slate, "bytes_per_slate": by_slate,
                          "hbm_achieved_GBps": round(ach_gb, 1), "hbm_frac_of_8TBps": round(ach_gb / PEAK_HBM_GBPS, 4),

@@ -1,6 +1,7 @@
 // ltr_fcw.h -- the fused slate pipeline of the TWO-LAYER scorer (136 -> 64 -> 1: the DoubleLayerNet variant of
-// architeture/doubleLayer.py:38-51 that BASELINE.json configs[0] / [1] name), re-laid-out for the f16 x 2 arithmetic of the
-// variant library (-DLTR_F16X2=1).  Included by ltr_scorer.hip inside its anonymous namespace.
+// architeture/doubleLayer.py:38-51 that BASELINE.json configs[0] / [1] name), feature-partitioned.  Two arithmetic versions of
+// the same layout, chosen at compile time: exact fp32 (v_mfma_f32_16x16x4_f32; the default library) and f16 x 2 (the variant
+// library, -DLTR_F16X2=1).  Included by ltr_scorer.hip inside its anonymous namespace.
 //
 // The generic pipeline (slate_pipeline_kernel) gives every wave 16 documents and ALL hidden units: every wave then reads every
 // weight, and dz has to be staged through LDS for the document contraction of dW.  Here the HIDDEN UNITS are partitioned instead
@@ -13,6 +14,16 @@
 //   * the scores need one exchange (each wave holds a 16-unit partial of w3 . h1): 2 KB through LDS.
 // 256 threads and 80 KB of LDS per workgroup -> TWO workgroups per CU: the listwise loss of one slate (barrier- and latency-bound,
 // matrix pipe idle) runs under the other workgroup's load / convert / MFMA phases.
+//
+// Exact fp32 version: X lives in LDS as fp32 rows of F + 4 floats (the ones feature and three zeros behind the F inputs; 140
+// floats: rows 12 banks apart, so both access patterns below are conflict-free).  For v_mfma_f32_16x16x4_f32 a lane holds ONE
+// value per operand, k-slot = lane >> 4, and the assignment of k-slots to features is free as long as both operands agree:
+//   * fc1 (z1[doc][n], A = x, B = W1): MFMA i of feature group S takes feature 16 S + 4 (lane >> 4) + i, so ONE ds_read_b128 of
+//     a document's row feeds four MFMAs and the resident B fragments are exactly the [64 lanes][4] tiles ltr_mlp_pack writes for
+//     the generic kernel (N::W1F_OFF): 36 VGPRs per wave, loaded once per kernel;
+//   * dW1 (A = dz1, B = x): the accumulator tile of fc1 -- lane (n, q) holds documents 4 q + r -- IS the A operand of MFMA r with
+//     k-slot q = document 4 q + r; B is one ds_read_b32 per MFMA, 16 consecutive floats of four rows: conflict-free.
+// 576 MFMAs per wave and tile (18.4 k cycles on its SIMD); no staging of dz through LDS, no weight stream.
 #pragma once
 
 #ifdef LTR_STAMPS
@@ -28,32 +39,51 @@ constexpr int kFcwThreads = kFcwWaves * 64;
 
 template <class N>
 constexpr size_t fcw_lds() {
+#if LTR_F16X2
     // X image pair [128][LD] halfs x 2 (+ 32 B so that the last k-step's over-read of the last row stays inside finite f16s),
     // 8 loss arrays [128], score partials [4][128], slate-group scratch [256 + 4*32], 16 exchange floats
     return (size_t)2 * kTileDocs * N::LD * 2 + 32 + sizeof(float) * (8 * kTileDocs + kFcwWaves * kTileDocs + kFcwThreads + 4 * 32 + 16);
+#else
+    // X [128][F + 4] fp32, 8 loss arrays [128], score partials [4][128], slate-group scratch [256 + 4*32]
+    return sizeof(float) * ((size_t)kTileDocs * (N::F + 4) + 8 * kTileDocs + kFcwWaves * kTileDocs + kFcwThreads + 4 * 32);
+#endif
 }
 
 template <class N, int LOSS>
 __global__ void __launch_bounds__(kFcwThreads, 2) fcw_fused_kernel(const PipeArgs a) {
     static_assert(N::TWO && N::H1 == 16 * kFcwWaves, "one hidden tile per wave");
-    constexpr int LDH = N::LD;                       // halfs per image row (72 dwords at LD = 144: conflict-free both ways)
-    constexpr int KP = N::KP1;                       // 32-wide k-steps over the features (+ the ones feature)
     constexpr int XT = N::XT;
     extern __shared__ __attribute__((aligned(16))) float smem_f[];
+#if LTR_F16X2
+    constexpr int LDH = N::LD;                       // halfs per image row (72 dwords at LD = 144: conflict-free both ways)
+    constexpr int KP = N::KP1;                       // 32-wide k-steps over the features (+ the ones feature)
     uint16_t *Xhi = reinterpret_cast<uint16_t *>(smem_f), *Xlo = Xhi + kTileDocs * LDH;
     float *sc = reinterpret_cast<float *>(Xlo + kTileDocs * LDH + 16);
+#else
+    constexpr int LDX = N::F + 4;                    // floats per X row: F inputs, the ones feature, three zeros
+    constexpr int LASTQ = (LDX - 16 * (XT - 1)) / 4; // 4-float groups of the last 16-feature tile that lie inside a row
+    static_assert(LDX % 8 == 4, "rows an odd number of 16-byte bank groups apart: conflict-free ds_read_b128 row fragments");
+    static_assert(LDX > 16 * (XT - 1) && LDX <= 16 * XT && LDX % 4 == 0, "the last feature tile starts inside the row");
+    float *Xs = smem_f;
+    float *sc = Xs + kTileDocs * LDX;
+#endif
     float *yl = sc + kTileDocs, *gn = yl + kTileDocs, *gg = gn + kTileDocs, *dsc = gg + kTileDocs, *uu = dsc + kTileDocs,
           *mk = uu + kTileDocs, *xt = mk + kTileDocs;
     float *part = xt + kTileDocs;                    // [4][128] per-wave score partials
     float *scratch = part + kFcwWaves * kTileDocs;   // [256 + 4*32]
+#if LTR_F16X2
     float *exch = scratch + kFcwThreads + 4 * 32;    // [16]
+#endif
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int q = lane >> 4, d = lane & 15;
     const int n_mine = 16 * w + d;                   // this lane's hidden unit (accumulator column)
 
-    // ---- once per kernel: resident W1 fragments, w3, zero pads of the images, loss scratch
+    // ---- once per kernel: resident W1 fragments, w3, pads of the X rows, loss scratch
+    const float w3n = a.packed[N::W3_OFF + n_mine];
+    const float b3 = a.packed[N::W3_OFF + N::NT2 * 16];
+#if LTR_F16X2
     h16x8 wh[KP], wl[KP];
     {
         const uint4 *src = reinterpret_cast<const uint4 *>(a.packed + N::W1B_OFF) + (size_t)w * KP * 2 * 64 + lane;
@@ -63,8 +93,6 @@ __global__ void __launch_bounds__(kFcwThreads, 2) fcw_fused_kernel(const PipeArg
             wl[P] = __builtin_bit_cast(h16x8, src[(2 * P + 1) * 64]);
         }
     }
-    const float w3n = a.packed[N::W3_OFF + n_mine];
-    const float b3 = a.packed[N::W3_OFF + N::NT2 * 16];
     const float inv_w1 = a.packed[N::W3_OFF + N::NT2 * 16 + 4];
     float w3max = 0.f;
     for (int j = lane; j < N::H2; j += 64) w3max = fmaxf(w3max, fabsf(a.packed[N::W3_OFF + j]));
@@ -75,12 +103,21 @@ __global__ void __launch_bounds__(kFcwThreads, 2) fcw_fused_kernel(const PipeArg
         Xlo[r * LDH + c] = 0;
     }
     if (tid < 16) Xlo[kTileDocs * LDH + tid] = 0;
+    int exx = 1, exd = -100, E = -400;
+#else
+    f32x4 wf[XT];                                    // lane (n, q): W1aug[16 w + n][16 S + 4 q .. + 3]
+    {
+        const f32x4 *src = reinterpret_cast<const f32x4 *>(a.packed + N::W1F_OFF) + (size_t)w * XT * 64 + lane;
+#pragma unroll
+        for (int S = 0; S < XT; ++S) wf[S] = src[S * 64];
+    }
+    for (int e = tid; e < kTileDocs * 4; e += kFcwThreads) Xs[(e >> 2) * LDX + N::F + (e & 3)] = (e & 3) ? 0.f : 1.f;
+#endif
     for (int j = tid; j < kFcwThreads + 4 * 32; j += kFcwThreads) scratch[j] = 0.f;
     f32x4 accW[XT];                                  // dW1 tiles (rows = my 16 hidden units, cols = 16 features each)
 #pragma unroll
     for (int t = 0; t < XT; ++t) accW[t] = f32x4{0.f, 0.f, 0.f, 0.f};
     float dw3 = 0.f, db3 = 0.f;
-    int exx = 1, exd = -100, E = -400;
 
     constexpr int V4_PER_ROW = N::F / 4, ROWS = kTileDocs / kFcwWaves, V4 = ROWS * V4_PER_ROW;   // this wave converts 32 rows
     constexpr int NV = (V4 + 63) / 64;
@@ -101,21 +138,26 @@ __global__ void __launch_bounds__(kFcwThreads, 2) fcw_fused_kernel(const PipeArg
             for (int m = 0; m < NV; ++m)
                 xn[m] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xr, lane * 16 + m * 1024, 0, 2 /* nt */));
         }
+#if LTR_F16X2
         float xm = 0.f;
 #pragma unroll
         for (int m = 0; m < NV; ++m)
 #pragma unroll
             for (int r = 0; r < 4; ++r) xm = fmaxf(xm, fabsf(xn[m][r]));
         xm = wave_allmax(xm);
+#endif
         FCW_STAMP(1)
         __syncthreads();                              // A: every wave is done with the previous tile's images, scores, gradients
+#if LTR_F16X2
         if (lane == 0) exch[w] = xm;
+#endif
         if (tid < kTileDocs) {
             const long long doc = doc_base + tid;
             const float y = doc < (long long)a.B * a.S ? a.labels[doc] : a.pad;
             if (LOSS != 1) stage_label(y, a.pad, yl[tid], gn[tid]);
             else yl[tid] = doc < (long long)a.B * a.S ? y : 0.f;
         }
+#if LTR_F16X2
         __syncthreads();                              // B: the four row-block maxima are out
         FCW_STAMP(2)
         {
@@ -140,10 +182,19 @@ __global__ void __launch_bounds__(kFcwThreads, 2) fcw_fused_kernel(const PipeArg
                 Xlo[(ROWS * w + lane) * LDH + N::F] = 0;
             }
         }
-        __syncthreads();                              // C: the image pair is complete
+#else
+        FCW_STAMP(2)
+#pragma unroll
+        for (int m = 0; m < NV; ++m) {                // rows of F floats -> rows of LDX floats (the pads were written once)
+            const int e = lane + 64 * m;
+            if (e < V4) *reinterpret_cast<f32x4 *>(Xs + (ROWS * w + e / V4_PER_ROW) * LDX + 4 * (e % V4_PER_ROW)) = xn[m];
+        }
+#endif
+        __syncthreads();                              // C: the tile is complete in LDS
         FCW_STAMP(3)
         // ---- fc1: z1[doc][n] for my 16 hidden units, all 8 document tiles; A = image rows, B = resident fragments
         f32x4 h1[8];
+#if LTR_F16X2
         {
             const uint16_t *rh = Xhi + d * LDH + 8 * q, *rl = Xlo + d * LDH + 8 * q;
             u32x4 fh[2][KP], fl[2][KP];              // A fragments of two document tiles: the reads of T+1 fly under the MFMAs of T
@@ -175,9 +226,43 @@ __global__ void __launch_bounds__(kFcwThreads, 2) fcw_fused_kernel(const PipeArg
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
+#else
+        {
+            // lane (doc, q) reads floats 16 S + 4 q .. + 3 of its document's row; in the last feature group the quads past the row
+            // (their W1 fragments are zero) are taken from the row's last quad instead (finite, and the lane's own row)
+            const float *ra = Xs + d * LDX + 4 * q;
+            const int last = 16 * (XT - 1) + (q < LASTQ ? 0 : 4 * (LASTQ - 1 - q));
+            f32x4 fa[2][XT];                          // A fragments of two document tiles: the reads of T+1 fly under the MFMAs of T
+#pragma unroll
+            for (int S = 0; S < XT; ++S) fa[0][S] = *reinterpret_cast<const f32x4 *>(ra + (S + 1 < XT ? 16 * S : last));
+#pragma unroll
+            for (int T = 0; T < 8; ++T) {
+                if (T + 1 < 8) {
+#pragma unroll
+                    for (int S = 0; S < XT; ++S)
+                        fa[(T + 1) & 1][S] = *reinterpret_cast<const f32x4 *>(ra + 16 * (T + 1) * LDX + (S + 1 < XT ? 16 * S : last));
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};      // two chains: 32-cycle issue vs 40-cycle dependent latency
+#pragma unroll
+                for (int S = 0; S < XT; ++S) {
+                    acc0 = mfma4(fa[T & 1][S][0], wf[S][0], acc0);
+                    acc1 = mfma4(fa[T & 1][S][1], wf[S][1], acc1);
+                    acc0 = mfma4(fa[T & 1][S][2], wf[S][2], acc0);
+                    acc1 = mfma4(fa[T & 1][S][3], wf[S][3], acc1);
+                }
+                h1[T] = acc0 + acc1;
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+#endif
         FCW_STAMP(4)
         // ---- activation (+ dropout), score partial w3 . h1 over my 16 units
+#if LTR_F16X2
         const float un = ldexpf(inv_w1, exx - 14);
+#else
+        const float un = 1.f;
+#endif
         const bool drop = (N::A1 == ACT_RELU_DROP) && a.dropout;
         long long left64 = a.n_docs - doc_base;
         const int docs_left = (int)(left64 > kTileDocs ? kTileDocs : left64);        // documents of this tile that exist (uniform)
@@ -254,9 +339,12 @@ __global__ void __launch_bounds__(kFcwThreads, 2) fcw_fused_kernel(const PipeArg
         FCW_STAMP(7)
         // ---- backward through fc3: dw3[n] += sum_doc ds h1, dz1 = ds w3 act'(h1); documents past the batch carry no gradient
         const float slope = drop ? a.drop_scale : 1.f;
+#if LTR_F16X2
         float dmx = fmaxf(fabsf(dsc[lane]), fabsf(dsc[lane + 64]));
         dmx = wave_allmax(dmx);
+#endif
         if (w == 0) db3 += wave_allsum((lane < docs_left ? dsc[lane] : 0.f) + (lane + 64 < docs_left ? dsc[lane + 64] : 0.f));
+#if LTR_F16X2
         exd = grow_exp(exd, dmx * slope * w3max);
         if (exd + exx != E) {
             const float f = ldexpf(1.f, E - (exd + exx));
@@ -265,6 +353,7 @@ __global__ void __launch_bounds__(kFcwThreads, 2) fcw_fused_kernel(const PipeArg
             E = exd + exx;
         }
         const float sd = ldexpf(1.f, 14 - exd);
+#endif
 #pragma unroll
         for (int T = 0; T < 8; ++T) {
             const f32x4 ds4 = *reinterpret_cast<const f32x4 *>(dsc + 16 * T + 4 * q);
@@ -276,6 +365,7 @@ __global__ void __launch_bounds__(kFcwThreads, 2) fcw_fused_kernel(const PipeArg
             }
         }
         FCW_STAMP(8)
+#if LTR_F16X2
         // ---- dW1[n][f] += sum_doc dz1[doc][n] x[doc][f]: A = two accumulator tiles of dz1 (split in registers), B = x k-major
         {
             const int lb = (4 * q + (d >> 2)) * LDH + 4 * (d & 3);
@@ -300,11 +390,41 @@ __global__ void __launch_bounds__(kFcwThreads, 2) fcw_fused_kernel(const PipeArg
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
+#else
+        // ---- dW1[n][f] += sum_doc dz1[doc][n] x[doc][f]: A = register r of the dz1 accumulator tile (k-slot q = document 4 q + r),
+        //      B = x[document 16 T + 4 q + r][16 Ti + d]; the last tile's columns past the row read the row's last float (a zero pad)
+        {
+            const float *rb = Xs + 4 * q * LDX + d;
+            const int lastc = 16 * (XT - 1) + (16 * (XT - 1) + d < LDX ? 0 : LDX - 1 - 16 * (XT - 1) - d);
+            // software pipeline over the 32 (document tile, register) steps: the nine B values of step s + 1 are in flight
+            // under the nine MFMAs (288 cycles) of step s -- left to itself the compiler reads each value right before its MFMA
+            float bx[2][XT];
+            auto load_b = [&](int step, float (&dst)[XT]) {
+                const float *pr = rb + (16 * (step >> 2) + (step & 3)) * LDX;
+#pragma unroll
+                for (int Ti = 0; Ti < XT; ++Ti) dst[Ti] = pr[Ti + 1 < XT ? 16 * Ti : lastc];
+            };
+            load_b(0, bx[0]);
+#pragma unroll
+            for (int step = 0; step < 32; ++step) {
+                if (step + 1 < 32) load_b(step + 1, bx[(step + 1) & 1]);
+                __builtin_amdgcn_sched_barrier(0);
+                const float av = h1[step >> 2][step & 3];
+#pragma unroll
+                for (int Ti = 0; Ti < XT; ++Ti) accW[Ti] = mfma4(av, bx[step & 1][Ti], accW[Ti]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+#endif
         FCW_STAMP(9)
     }
     // ---- per-workgroup partial gradients -> workspace (the layout reduce_grads_kernel<N> sums)
     float *out = a.partials + (size_t)blockIdx.x * N::PART;
+#if LTR_F16X2
     const float us = ldexpf(1.f, E - 28);
+#else
+    const float us = 1.f;
+#endif
 #pragma unroll
     for (int Ti = 0; Ti < XT; ++Ti)
 #pragma unroll

@@ -809,9 +809,7 @@ __device__ __forceinline__ void dma_x_rows(const PipeArgs &a, float *Xs, long lo
     }
 }
 
-#if LTR_F16X2
 #include "ltr_fcw.h"
-#endif
 
 template <class N, int MODE, int LOSS>
 __global__ void __launch_bounds__(kThreads, 2) slate_pipeline_kernel(const PipeArgs a) {
@@ -1643,7 +1641,6 @@ int pipeline_dispatch(int mode, const PipeArgs &a, int grid, hipStream_t stream)
         case MODE_BWD: return launch_pipeline<N, MODE_BWD, 0>(a, grid, stream);
         case MODE_BWD_SAVED: return launch_pipeline<N, MODE_BWD_SAVED, 0>(a, grid, stream);
         default:
-#if LTR_F16X2
             if constexpr (N::TWO) {      // two-layer nets: the feature-partitioned kernel, two workgroups per CU (ltr_fcw.h)
                 switch (a.loss_kind) {
                     case 0: return launch_fcw<N, 0>(a, grid, stream);
@@ -1651,7 +1648,6 @@ int pipeline_dispatch(int mode, const PipeArgs &a, int grid, hipStream_t stream)
                     default: return launch_fcw<N, 2>(a, grid, stream);
                 }
             }
-#endif
             switch (a.loss_kind) {
                 case 0: return launch_pipeline<N, MODE_FUSED, 0>(a, grid, stream);
                 case 1: return launch_pipeline<N, MODE_FUSED, 1>(a, grid, stream);
@@ -1677,9 +1673,7 @@ int ltr_net_info(int net, int32_t *info) {
 int ltr_fused_grid(int net, int n_cus) {
     if (n_cus < 1) return LTR_ERR_PARAM;
     if (net < LTR_NET_DOUBLE || net > LTR_NET_TWO_LAYER_64H) return LTR_ERR_PARAM;
-#if LTR_F16X2
-    if (net == LTR_NET_TWO_LAYER_64H) return 2 * n_cus;       /* 256-thread workgroups, two per CU */
-#endif
+    if (net == LTR_NET_TWO_LAYER_64H) return 2 * n_cus;       /* 256-thread workgroups, two per CU (ltr_fcw.h) */
     return n_cus;
 }
 

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Phase stamps of the feature-partitioned two-layer kernel (csrc/ltr_fcw.h; -DLTR_F16X2=1 -DLTR_STAMPS build via LTR_LIB):
+"""Phase stamps of the feature-partitioned two-layer kernel (csrc/ltr_fcw.h; a -DLTR_STAMPS build of either library via LTR_LIB):
 cycles per phase of one mid-run tile, median over workgroups and the 4 waves, at 1 and at 2 workgroups per CU."""
 import json, os, sys
 import torch
@@ -9,8 +9,8 @@ from ltr_mi355x import lib, scorer  # noqa: E402
 from ltr_mi355x.extra_nets import TwoLayerNet  # noqa: E402
 from ltr_mi355x.functional import _ptr, _stream, check  # noqa: E402
 
-NAMES = ["X loads -> registers (+max)", "barrier A + labels + barrier B", "convert -> images + barrier C", "fc1 (40 MFMA x 8 tiles... 160)",
-         "activation + score partials", "barrier D + score sum + barrier", "loss", "dz1 (+dw3, scales)", "dW1 (144 MFMA)"]
+NAMES = ["X loads -> registers (+max)", "barrier A + labels (+ barrier B)", "X -> LDS (convert) + barrier C", "fc1 (fp32: 288 MFMA x 32 cyc; f16x2: 160 x 16)",
+         "activation + score partials", "barrier D + score sum + barrier", "loss", "dz1 (+dw3, scales)", "dW1 (fp32: 288 MFMA; f16x2: 144)"]
 dev = torch.device("cuda:0")
 B, S = 25_000, 128
 X = torch.randn(B, S, 136, device=dev)
