@@ -1694,7 +1694,7 @@ __device__ __forceinline__ void softmax_tile(f32x4 (&st)[KTMAX], int KT, const f
 
 // FULL: the padded slate fills all KTMAX key tiles (the `kt < KT` guards fold away)
 template <int KTMAX, bool FULL>
-__global__ void __launch_bounds__(kAttThreads) attention_fwd_kernel(AttArgs a) {
+__global__ void __launch_bounds__(kAttThreads, (KTMAX <= 16 ? 3 : 1)) attention_fwd_kernel(AttArgs a) {   // S <= 256: 3 workgroups per CU (170 VGPRs, 38 KB of LDS each)
     extern __shared__ __attribute__((aligned(16))) bf16_t smem[];
     const int Sp = round_up(a.S, 32), KT = FULL ? KTMAX : Sp / 16, ldt = tr_ld(Sp);
     bf16_t *Kimg = smem, *VT = Kimg + Sp * kRowLd;
@@ -1702,7 +1702,8 @@ __global__ void __launch_bounds__(kAttThreads) attention_fwd_kernel(AttArgs a) {
     int b, hd;
     if (!att_slate_head(a.B, a.h, b, hd)) return;
     const int d = a.h * a.dk, bh = b * a.h + hd;          // bh: index of this (slate, head) in the dropout stream
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, j = lane & 15, g = lane >> 4;
+    const int lane = threadIdx.x & 63, j = lane & 15, g = lane >> 4;
+    const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));      // wave-uniform: scalar tile loops
     const bool vec = a.dk % 8 == 0;
     stage_head(a, b, hd, 1, Sp, Kimg, nullptr, 0);
     stage_head(a, b, hd, 2, Sp, nullptr, VT, ldt);
@@ -1781,7 +1782,8 @@ __global__ void __launch_bounds__(kAttThreads) attention_bwd_kernel(AttArgs a) {
     int b, hd;
     if (!att_slate_head(a.B, a.h, b, hd)) return;
     const int d = a.h * a.dk, bh = b * a.h + hd;
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, j = lane & 15, g = lane >> 4;
+    const int lane = threadIdx.x & 63, j = lane & 15, g = lane >> 4;
+    const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));      // wave-uniform: scalar tile loops
     const bool vec = a.dk % 8 == 0;
     const float scale = 1.f / sqrtf((float)a.dk), c2 = 1.44269504088896341f * scale;
     const unsigned thr = drop_threshold(a.drop_p);

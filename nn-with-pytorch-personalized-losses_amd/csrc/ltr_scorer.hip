@@ -780,6 +780,9 @@ __device__ __forceinline__ void load_x_tile(f32x4 (&xr)[kXV4<N>()], const PipeAr
     }
 }
 
+#ifndef LTR_LOSS_UNR
+#define LTR_LOSS_UNR 1           // trips of 8 columns unrolled in the approxNDCG sweeps of the 136-wide nets: 2 costs 72 B/lane more scratch and 2 % (profiles/r03_variant_ab.json)
+#endif
 #ifndef LTR_XDMA
 #define LTR_XDMA 1
 #endif
@@ -1157,10 +1160,10 @@ __global__ void __launch_bounds__(kThreads, 2) slate_pipeline_kernel(const PipeA
                 ApproxScratch xs;               // enables the no-clamp path (4 pair terms per v_rcp, histogram ideal DCG)
                 xs.um = xt + so;
                 if (a.S == 128)
-                    loss = approx_ndcg_slate<32, (N::H1 <= 64 ? 4 : 2)>(g, sc + so, yl + so, gn + so, gg + so, uu + so, mk + so, a.alpha,
+                    loss = approx_ndcg_slate<32, (N::H1 <= 64 ? 4 : LTR_LOSS_UNR)>(g, sc + so, yl + so, gn + so, gg + so, uu + so, mk + so, a.alpha,
                                                  a.eps, a.gscale, true, st_ds, stamp_fn, xs);
                 else if (a.S == 64)
-                    loss = approx_ndcg_slate<16, (N::H1 <= 64 ? 4 : 2)>(g, sc + so, yl + so, gn + so, gg + so, uu + so, mk + so, a.alpha,
+                    loss = approx_ndcg_slate<16, (N::H1 <= 64 ? 4 : LTR_LOSS_UNR)>(g, sc + so, yl + so, gn + so, gg + so, uu + so, mk + so, a.alpha,
                                                  a.eps, a.gscale, true, st_ds, NoStamp(), xs);
                 else
                     loss = approx_ndcg_slate<8>(g, sc + so, yl + so, gn + so, gg + so, uu + so, mk + so, a.alpha,

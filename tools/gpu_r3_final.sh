@@ -7,11 +7,16 @@ TAG=${1:-r3fin}; OUT=gpurun_out; mkdir -p $OUT
 REPO=${GRAFT_REPO_ROOT:-/root/repo}
 V=$PWD/nn-with-pytorch-personalized-losses_amd/ltr_mi355x/libltr_mi355x_f16x2.so
 run() { local name=$1 to=$2; shift 2; timeout -k 10 $to "$@" > $OUT/${TAG}_$name.log 2>&1; local rc=$?; echo "[$name] exit $rc"; if [ $rc -eq 124 ] || [ $rc -eq 137 ]; then echo "TIMED OUT"; exit 9; fi; return $rc; }
+PART=${2:-all}      # tests | bench | prof | all  (three gpurun calls fit the 1200 s limit comfortably)
+if [ $PART = tests ] || [ $PART = all ]; then
 run tests 1000 python -m pytest tests -m gpu -q; grep -E "passed|failed" $OUT/${TAG}_tests.log | tail -1; grep -E "^FAILED" $OUT/${TAG}_tests.log | head
 cp $OUT/parity_report.json $OUT/${TAG}_parity_report.json 2>/dev/null
 LTR_LIB=$V run tests_f16x2 1000 python -m pytest tests -m gpu -q; grep -E "passed|failed" $OUT/${TAG}_tests_f16x2.log | tail -1; grep -E "^FAILED" $OUT/${TAG}_tests_f16x2.log | head
 cp $OUT/parity_report.json $OUT/${TAG}_parity_report_f16x2.json 2>/dev/null
 run smoke 300 python __graft_entry__.py smoke; tail -2 $OUT/${TAG}_smoke.log
+fi
+[ $PART = tests ] && exit 0
+if [ $PART = bench ] || [ $PART = all ]; then
 run bench 900 python bench.py --steps 20 --warmup 3; tail -1 $OUT/${TAG}_bench.log | cut -c1-300
 for lib in fp32 f16x2; do
   if [ $lib = f16x2 ]; then export LTR_LIB=$V; else unset LTR_LIB; fi
@@ -24,9 +29,15 @@ done
 unset LTR_LIB
 run bench_losses 300 python tools/bench_losses.py; grep -E "approx|lambda" $OUT/${TAG}_bench_losses.log
 run bench_c5 300 python tools/bench_encoder.py --batch 256 --steps 10 --warmup 3; tail -1 $OUT/${TAG}_bench_c5.log | cut -c1-300
-for v in fp32new_stamps f16x2_stamps; do
+run bench_aux 300 python tools/bench_aux.py; grep -c . $OUT/${TAG}_bench_aux.log
+run bench_enc_kernels 200 python tools/bench_encoder_kernels.py; grep -c kernel $OUT/${TAG}_bench_enc_kernels.log
+run enc_parity 300 python tools/enc_parity_report.py; grep -c case $OUT/${TAG}_enc_parity.log
+for v in fp32_stamps f16x2_stamps; do        # tools/build_variant.sh fp32_stamps -DLTR_STAMPS ; ... f16x2_stamps -DLTR_F16X2=1 -DLTR_STAMPS
   [ -f variants/$v.so ] && LTR_LIB=$PWD/variants/$v.so timeout -k 10 200 python tools/phase_stamps.py > $OUT/${TAG}_stamps_$v.jsonl 2>/dev/null; echo "[stamps $v] exit $?"
+  [ -f variants/$v.so ] && LTR_LIB=$PWD/variants/$v.so timeout -k 10 200 python tools/fcw_stamps.py > $OUT/${TAG}_fcw_stamps_$v.jsonl 2>/dev/null; echo "[fcw stamps $v] exit $?"
 done
+fi
+[ $PART = bench ] && exit 0
 cd /tmp && export TMPDIR=/tmp
 for lib in fp32 f16x2; do
   if [ $lib = f16x2 ]; then export LTR_LIB=$V; else unset LTR_LIB; fi

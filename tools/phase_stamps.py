@@ -18,7 +18,7 @@ B, S = 25_000, 128
 X = torch.randn(B, S, 136, device=dev)
 y = torch.randint(0, 5, (B, S), device=dev).float()
 h = lib()
-for name, cls in (("double", DoubleLayerNet), ("triple", TripleLayerNet), ("two64", TwoLayerNet)):
+for name, cls in (("double", DoubleLayerNet), ("triple", TripleLayerNet)):      # the 136-64-1 net: tools/fcw_stamps.py
     net = cls(136).to(dev).eval()
     info = scorer.NetInfo.get(net._ltr_net)
     packed = scorer.pack_params(net._ltr_net, net._ltr_params())
