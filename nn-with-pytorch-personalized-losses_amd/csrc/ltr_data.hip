@@ -27,7 +27,8 @@ namespace {
 
 // ------------------------------------------------------------------------------------------ device gather
 // dst[r][:] = src[idx[r]][:], rows of `row_f4` float4s.  One workgroup handles kRowsPerBlock destination rows;
-// lanes sweep a row in 16-byte pieces (fully coalesced on both sides).
+// lanes sweep a row in 16-byte pieces (fully coalesced on both sides).  Negative indices count from the end like torch
+// indexing (idx + src_rows); an index still out of range yields a ZERO row (torch raises a device-side assert there).
 constexpr int kGatherThreads = 256;
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -38,8 +39,9 @@ gather_rows_kernel(const f32x4 *__restrict__ src, const int64_t *__restrict__ id
     for (int64_t e = (int64_t)blockIdx.x * kGatherThreads + threadIdx.x; e < total; e += (int64_t)gridDim.x * kGatherThreads) {
         const int64_t r = e / row_f4;
         const int c = (int)(e - r * row_f4);
-        const int64_t s = idx[r];
-        if (s >= 0 && s < src_rows) dst[e] = __builtin_nontemporal_load(src + s * row_f4 + c);
+        int64_t s = idx[r];
+        if (s < 0) s += src_rows;
+        dst[e] = s >= 0 && s < src_rows ? __builtin_nontemporal_load(src + s * row_f4 + c) : f32x4{0.f, 0.f, 0.f, 0.f};
     }
 }
 
@@ -52,15 +54,16 @@ gather_rows_wide_kernel(const f32x4 *__restrict__ src, const int64_t *__restrict
     for (int64_t b = blockIdx.x; b < n_rows * pieces; b += gridDim.x) {
         const int64_t r = b / pieces;
         const int piece = (int)(b - r * pieces);
-        const int64_t srow = idx[r];
-        if (srow < 0 || srow >= src_rows) continue;
-        const f32x4 *sp = src + srow * row_f4;
+        int64_t srow = idx[r];
+        if (srow < 0) srow += src_rows;
+        const bool ok = srow >= 0 && srow < src_rows;
+        const f32x4 *sp = src + (ok ? srow : 0) * row_f4;
         f32x4 *dp = dst + r * row_f4;
         const int c0 = piece * kGatherPiece + threadIdx.x;
         f32x4 v[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k)
-            if (c0 + k * kGatherThreads < row_f4) v[k] = __builtin_nontemporal_load(sp + c0 + k * kGatherThreads);
+            if (c0 + k * kGatherThreads < row_f4) v[k] = ok ? __builtin_nontemporal_load(sp + c0 + k * kGatherThreads) : f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int k = 0; k < 4; ++k)
             if (c0 + k * kGatherThreads < row_f4) __builtin_nontemporal_store(v[k], dp + c0 + k * kGatherThreads);
@@ -74,8 +77,9 @@ gather_rows_scalar_kernel(const float *__restrict__ src, const int64_t *__restri
     for (int64_t e = (int64_t)blockIdx.x * kGatherThreads + threadIdx.x; e < total; e += (int64_t)gridDim.x * kGatherThreads) {
         const int64_t r = e / row_f;
         const int c = (int)(e - r * row_f);
-        const int64_t s = idx[r];
-        if (s >= 0 && s < src_rows) dst[e] = src[s * row_f + c];
+        int64_t s = idx[r];
+        if (s < 0) s += src_rows;
+        dst[e] = s >= 0 && s < src_rows ? src[s * row_f + c] : 0.f;
     }
 }
 

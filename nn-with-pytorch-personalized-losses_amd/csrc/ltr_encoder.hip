@@ -51,18 +51,26 @@ __device__ __forceinline__ unsigned mix32(unsigned h) {
     return h;
 }
 // 32 hash bits shared by the FOUR elements 4*quad .. 4*quad + 3 of stream `stream_id`: one murmur3 finaliser over the quad
-// counter xor a per-(seed, stream) key (wave-uniform, hoisted out of every loop by the compiler).  Element r of the quad
+// counter under two per-(seed, stream) keys (below).  Element r of the quad
 // is kept when the 16-bit window of the word starting at byte r (low byte r, high byte r+1 mod 4: each byte is the HIGH byte
 // of one element and the tie-break LOW byte of its neighbour) is >= the threshold p * 65536: every element's window is an
 // exactly uniform 16-bit number (two distinct bytes of a uniform word), so the keep probability is exactly
 // 1 - thr / 65536, and a neighbour's byte decides an element only in the 1 / 256 of cases where its own high byte ties
 // the threshold's.  Half the multiplies per element of one word per pair (the hash is ~20 % of the fused-FFN and ~25 %
 // of the attention kernels' time at p > 0); the statistics are tested in tests/test_encoder_gpu.py.
-__device__ __forceinline__ unsigned drop_key(unsigned long long seed, int stream_id) {
-    return mix32((unsigned)seed ^ (0x9E3779B9u * (unsigned)(stream_id + 1))) ^ mix32((unsigned)(seed >> 32) + 0x85EBCA6Bu * (unsigned)stream_id);
+// TWO 32-bit keys per (seed, stream): k0 is xored into the counter, k1 is ADDED between the two multiplies of the finaliser, so the
+// streams of two (seed, stream) pairs are not XOR-translations of one fixed sequence (they would be with a single key folded in
+// in front: mask_A[i] == mask_B[i ^ delta]).  Both are wave-uniform and hoisted out of every loop; the cost is one add per word.
+__device__ __forceinline__ unsigned drop_key0(unsigned long long seed, int stream_id) {
+    return mix32((unsigned)seed ^ (0x9E3779B9u * (unsigned)(stream_id + 1)));
+}
+__device__ __forceinline__ unsigned drop_key1(unsigned long long seed, int stream_id) {
+    return mix32((unsigned)(seed >> 32) + 0x85EBCA6Bu * (unsigned)stream_id + 0x165667B1u);
 }
 __device__ __forceinline__ unsigned drop_word(unsigned long long seed, int stream_id, unsigned long long quad) {
-    return mix32((unsigned)quad ^ drop_key(seed, stream_id) ^ (0x27D4EB2Fu * (unsigned)(quad >> 32)));
+    unsigned h = (unsigned)quad ^ drop_key0(seed, stream_id) ^ (0x27D4EB2Fu * (unsigned)(quad >> 32));
+    h ^= h >> 16; h *= 0x85EBCA6Bu; h += drop_key1(seed, stream_id); h ^= h >> 13; h *= 0xC2B2AE35u; h ^= h >> 16;
+    return h;
 }
 __host__ __device__ inline unsigned drop_threshold(float p) {
     if (!(p > 0.f)) return 0u;

@@ -56,7 +56,8 @@ def group_by_query(rows, bounds):
 
 def gather_rows(src, idx, out=None):
     """out[r] = src[idx[r]] over the leading dimension, on the device (the per-epoch `X_train[idx]` of
-    main_batch_execution.py:112-117).  src fp32 device tensor, idx int64 device tensor."""
+    main_batch_execution.py:112-117).  src fp32 device tensor, idx int64 device tensor.  Negative indices count from the end as
+    in torch indexing; an index that is still out of range gives a zero row (torch raises a device-side assert)."""
     require_device(src, idx)
     if src.dtype != torch.float32:
         raise TypeError(f"gather_rows moves fp32 rows, got {src.dtype}")

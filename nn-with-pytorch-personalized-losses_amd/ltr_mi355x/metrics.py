@@ -30,7 +30,10 @@ def to_device_f32(a, like=None):
 
 def ndcg_at_k(y_true, y_score, k=5, no_relevant=True, gains="linear", reverse_ties=False, want="ndcg"):
     """Per-query NDCG@k (want="ndcg") or un-normalised DCG@k (want="dcg"), [Q] fp64 device tensor
-    (utils/metrics.py:48-80).  y_true, y_score: [Q, S]."""
+    (utils/metrics.py:48-80).  y_true, y_score: [Q, S].  Labels and scores are RANKED IN FP32 (the reference's numpy path ranks
+    whatever dtype it is given, float64 included): float64 scores that differ below fp32 resolution become ties here and are then
+    ordered by index.  The accumulation and the result are fp64.  Parity unpinned for such inputs: the reference's fixtures and
+    this repo's goldens only hold fp32-representable values."""
     if gains not in GAINS:
         raise ValueError("Invalid gains option.")                                  # metrics.py:62
     s = to_device_f32(y_score)

@@ -115,6 +115,13 @@ def test_gather_rows(shape, dev):
         cur_x, cur_y = nx.clone(), ny.clone()
     with pytest.raises(ValueError):
         gather_rows(src, idx, out=src)
+    # negative indices count from the end (torch semantics); an index still out of range gives a zero row (torch asserts)
+    neg = torch.tensor([-1, 0, -shape[0], shape[0] - 1], device=dev)
+    assert torch.equal(gather_rows(src, neg), src[neg])
+    bad = torch.tensor([0, shape[0], -shape[0] - 1, 1 % shape[0]], device=dev)
+    got = gather_rows(src, bad)
+    assert torch.equal(got[0], src[0]) and torch.equal(got[3], src[1 % shape[0]])
+    assert float(got[1].abs().max()) == 0.0 and float(got[2].abs().max()) == 0.0
 
 
 def test_gather_bandwidth_smoke(dev):
