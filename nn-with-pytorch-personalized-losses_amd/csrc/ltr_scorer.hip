@@ -323,82 +323,8 @@ __device__ __forceinline__ void gemm_wx_h(__amdgpu_buffer_rsrc_t rsrc, int base_
     for (int To = 0; To < NT; ++To) out[To] *= un;
 }
 
-// ---- the same GEMM with the weight fragments SHARED through LDS (backward / fused kernels of the 136-wide nets).
-// Streaming them L2 -> registers per wave (gemm_wx_h) is bound by the CU's 64 B/clk vector-memory path: 8 waves x 2 KiB per
-// (k-step, tile) against 96 matrix-pipe cycles.  Here a GEMM's fragments travel ONCE per workgroup, L2 -> LDS by LDS-DMA, in
-// chunks of two k-steps (<= 36 KiB) that ping-pong between the two halves of the dW staging region (idle outside the dW
-// phases); all 8 waves read them with conflict-free ds_read_b128.  One wait + barrier per chunk: it publishes chunk c and
-// retires chunk c-1, whose buffer then receives chunk c+1 (or the next GEMM's chunk 0) while chunk c is being multiplied.
-constexpr int kWBufFloats = 9216;            // 36 KiB
-constexpr int kPPC = 2;                      // k-steps per chunk
-typedef __attribute__((address_space(1))) const void *w_gptr_t;
-typedef __attribute__((address_space(3))) void *w_lptr_t;
-
-template <int NT, int KP>
-__device__ __forceinline__ void dma_wchunk(const float *sec, int c, float *buf, int w, int lane) {
-    static_assert(kPPC * NT * 2 * 256 <= kWBufFloats, "a chunk must fit one 36 KiB buffer");
-    const int p0 = c * kPPC * NT * 2;                                          // first 1 KiB piece of the chunk
-    const int np = (KP - c * kPPC < kPPC ? KP - c * kPPC : kPPC) * NT * 2;
-    for (int i = w; i < np; i += kWaves)
-        __builtin_amdgcn_global_load_lds((w_gptr_t)(sec + (size_t)(p0 + i) * 256 + lane * 4), (w_lptr_t)(buf + i * 256), 16, 0, 0);
-}
-
-// PAR: which buffer holds chunk 0 (its DMA was ISSUED by the caller).  issue_next(buf) is called once, when the last chunk
-// has been published, with the buffer that is free from then on.
-template <int NT, int KT, int PAR, int KMAX, int NMAX, class Next>
-__device__ __forceinline__ void gemm_wx_hl(const float *sec, float *Wb, int w, int lane, const f32x4 (&bin)[KMAX],
-                                           f32x4 (&out)[NMAX], float inv_w, Next issue_next) {
-    constexpr int KP = (KT + 1) / 2;
-    constexpr int NCH = (KP + kPPC - 1) / kPPC;
-    float m = 0.f;
-#pragma unroll
-    for (int T = 0; T < KT; ++T)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) m = fmaxf(m, fabsf(bin[T][r]));
-    m = fmaxf(m, __shfl_xor(m, 16, 64));
-    m = fmaxf(m, __shfl_xor(m, 32, 64));
-    int e = __builtin_amdgcn_frexp_expf(m);
-    e = e < -100 ? -100 : e;
-    const float sc = ldexpf(1.f, 14 - e);
-    const float un = ldexpf(inv_w, e - 14);
-#pragma unroll
-    for (int To = 0; To < NT; ++To) out[To] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int c = 0; c < NCH; ++c) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        float *nb = Wb + (((PAR + c + 1) & 1) ? kWBufFloats : 0);
-        if (c + 1 < NCH) dma_wchunk<NT, KP>(sec, c + 1, nb, w, lane);
-        else issue_next(nb);
-        const float *cb = Wb + (((PAR + c) & 1) ? kWBufFloats : 0) + lane * 4;
-#pragma unroll
-        for (int Pl = 0; Pl < kPPC; ++Pl) {
-            const int P = c * kPPC + Pl;
-            if (P < KP) {
-                h16x8 bhi, blo;
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const int T = 2 * P + (j >> 2);
-                    const float v = (T < KT ? bin[T < KT ? T : 0][j & 3] : 0.f) * sc;
-                    const _Float16 h = (_Float16)v;
-                    bhi[j] = h;
-                    blo[j] = (_Float16)(v - (float)h);
-                }
-#pragma unroll
-                for (int To = 0; To < NT; ++To) {
-                    const h16x8 ahi = __builtin_bit_cast(h16x8, *reinterpret_cast<const f32x4 *>(cb + ((Pl * NT + To) * 2) * 256));
-                    const h16x8 alo = __builtin_bit_cast(h16x8, *reinterpret_cast<const f32x4 *>(cb + ((Pl * NT + To) * 2 + 1) * 256));
-                    out[To] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ahi, bhi, out[To], 0, 0, 0);
-                    out[To] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ahi, blo, out[To], 0, 0, 0);
-                    out[To] = __builtin_amdgcn_mfma_f32_16x16x32_f16(alo, bhi, out[To], 0, 0, 0);
-                    if (LTR_LOLO) out[To] = __builtin_amdgcn_mfma_f32_16x16x32_f16(alo, blo, out[To], 0, 0, 0);
-                }
-            }
-        }
-    }
-#pragma unroll
-    for (int To = 0; To < NT; ++To) out[To] *= un;
-}
+// (Sharing these fragments through LDS instead -- LDS-DMA chunks of two k-steps ping-ponging in the dW staging region, three chunk
+// barriers per GEMM -- was built and measured no faster than this L2 stream: profiles/r03_variant_ab.json, step 2.  Removed.)
 
 #endif
 
@@ -866,16 +792,10 @@ __global__ void __launch_bounds__(kThreads, 2) slate_pipeline_kernel(const PipeA
     constexpr bool XPREF = x_reg_prefetch<N, MODE>();
     constexpr bool XDMA = LTR_XDMA && !XPREF;
 #if LTR_F16X2
-#ifndef LTR_WLDS
-#define LTR_WLDS 0               // 1: fc1 / fc2 / dh1 weight fragments shared through LDS (gemm_wx_hl; A/B: no faster than L2 streaming)
-#endif
 #ifndef LTR_DWH
 #define LTR_DWH 1                // 1: the weight-gradient GEMMs on the f16 matrix cores too (step 3)
 #endif
     constexpr bool DWH = LTR_DWH && MODE != MODE_FWD && (XDMA || XPREF);
-    constexpr bool WLDS = LTR_WLDS && !DWH && N::H1 > 64 && MODE != MODE_FWD && XDMA;
-    float *Wb = Ds;                                                    // two 36 KiB buffers = the dW staging region
-    static_assert(!WLDS || 2 * kWBufFloats <= 2 * kChunkDocs * N::LD, "the two weight buffers live in the dW staging region");
     constexpr int LDH = LD;                                            // halfs per row of an f16 image (LD / 2 dwords: 8 mod 64 at LD = 144)
     uint16_t *Xhi = reinterpret_cast<uint16_t *>(Xs), *Xlo = Xhi + kTileDocs * LDH;   // X as hi / lo images: the bytes of the fp32 tile
     uint16_t *Sg = reinterpret_cast<uint16_t *>(Ds);                   // staging images (and the landing zone of the X DMA)
@@ -884,7 +804,6 @@ __global__ void __launch_bounds__(kThreads, 2) slate_pipeline_kernel(const PipeA
     float w3max = 0.f;
 #else
     constexpr bool DWH = false;
-    constexpr bool WLDS = false;
 #endif
     f32x4 xn[kXV4<N>()];
 #if LTR_F16X2
@@ -985,9 +904,6 @@ __global__ void __launch_bounds__(kThreads, 2) slate_pipeline_kernel(const PipeA
 #endif
         if (XDMA) {
             dma_x_rows<N>(a, Xs, doc_base + 16 * w, w, lane);
-#if LTR_F16X2
-            if (WLDS && MODE != MODE_BWD_SAVED) dma_wchunk<N::NT1, N::KP1>(a.packed + N::W1H_OFF, 0, Wb, w, lane);   // fc1 chunk 0
-#endif
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         } else {
             // register-prefetch kernels: only the first tile is loaded here, later ones arrive ahead of time
@@ -1062,11 +978,7 @@ __global__ void __launch_bounds__(kThreads, 2) slate_pipeline_kernel(const PipeA
                 xb[T] = *reinterpret_cast<const f32x4 *>(Xs + my_row * LD + 16 * T + 4 * q);
             if (N::H1T > N::NT1) h1[N::H1T - 1] = f32x4{0.f, 0.f, 0.f, 0.f};
 #if LTR_F16X2
-            if (WLDS)
-                gemm_wx_hl<N::NT1, N::XT, 0>(a.packed + N::W1H_OFF, Wb, w, lane, xb, h1, w3s[N::NT2 * 16 + 4], [&](float *nb) {
-                    if (!N::TWO) dma_wchunk<N::NT2, N::KP2>(a.packed + N::W2H_OFF, 0, nb, w, lane);                 // fc2 chunk 0
-                });
-            else if (!LTR_SKIP(a, 16)) gemm_wx_h<N::NT1, N::XT>(wrsrc, N::W1H_OFF * 4, lane_off, xb, h1, w3s[N::NT2 * 16 + 4]);
+            if (!LTR_SKIP(a, 16)) gemm_wx_h<N::NT1, N::XT>(wrsrc, N::W1H_OFF * 4, lane_off, xb, h1, w3s[N::NT2 * 16 + 4]);
 #else
             if (!LTR_SKIP(a, 16)) gemm_wx<N::NT1, N::XT>(wrsrc, N::W1F_OFF * 4, lane_off, xb, h1);
 #endif
@@ -1102,10 +1014,7 @@ __global__ void __launch_bounds__(kThreads, 2) slate_pipeline_kernel(const PipeA
             for (int To = 0; To < N::NT2; ++To) h2[To] = h1[To];
         } else {
 #if LTR_F16X2
-            if (WLDS)      // chunk 0 sits in the buffer fc1's last chunk left free: (0 + NCH1) & 1
-                gemm_wx_hl<N::NT2, N::H1T, ((N::KP1 + kPPC - 1) / kPPC) & 1>(a.packed + N::W2H_OFF, Wb, w, lane, h1, h2, w3s[N::NT2 * 16 + 5],
-                                                                            [&](float *) {});
-            else if (!LTR_SKIP(a, 8)) gemm_wx_h<N::NT2, N::H1T>(wrsrc, N::W2H_OFF * 4, lane_off, h1, h2, w3s[N::NT2 * 16 + 5]);
+            if (!LTR_SKIP(a, 8)) gemm_wx_h<N::NT2, N::H1T>(wrsrc, N::W2H_OFF * 4, lane_off, h1, h2, w3s[N::NT2 * 16 + 5]);
 #else
             if (!LTR_SKIP(a, 8)) gemm_wx<N::NT2, N::H1T>(wrsrc, N::W2F_OFF * 4, lane_off, h1, h2);
 #endif
@@ -1315,11 +1224,7 @@ __global__ void __launch_bounds__(kThreads, 2) slate_pipeline_kernel(const PipeA
             for (int To = 0; To < N::NT1; ++To) dz1[To] = h2[To];
         }
 #if LTR_F16X2
-        else if (WLDS) {
-            __syncthreads();                       // every wave is done reading Ds / Hs (dW2 chunk 1): the region is free
-            dma_wchunk<N::NT1, N::KPT>(a.packed + N::W2TH_OFF, 0, Wb, w, lane);
-            gemm_wx_hl<N::NT1, N::NT2, 0>(a.packed + N::W2TH_OFF, Wb, w, lane, h2, dz1, w3s[N::NT2 * 16 + 6], [&](float *) {});
-        } else if (!LTR_SKIP(a, 4)) gemm_wx_h<N::NT1, N::NT2>(wrsrc, N::W2TH_OFF * 4, lane_off, h2, dz1, w3s[N::NT2 * 16 + 6]);
+        else if (!LTR_SKIP(a, 4)) gemm_wx_h<N::NT1, N::NT2>(wrsrc, N::W2TH_OFF * 4, lane_off, h2, dz1, w3s[N::NT2 * 16 + 6]);
 #else
         else if (!LTR_SKIP(a, 4)) gemm_wx<N::NT1, N::NT2>(wrsrc, N::W2T_OFF * 4, lane_off, h2, dz1);
 #endif
