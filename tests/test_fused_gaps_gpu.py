@@ -47,7 +47,30 @@ def test_bench_batch_train_mode_vs_fp64_oracle(dev):
     e = relerr(out.cpu().numpy(), rl)
     ledger_record("bench-batch loss (2048 x 128, train mode)", e)
     assert e < TOL
-    assert_grads(_grads(net), rg, ref32=rg32)
+    got = _grads(net)
+    assert_grads(got, rg, ref32=rg32)
+    # What the relaxed bar above absorbs is NOT accumulation error (tools/diag_bench_batch.py, profiles/r03_bench_batch_gradient_deviation.jsonl):
+    # fc2.weight deviates by 1.8e-3 of its own max, and 99.99995 % of that deviation is ONE rank-one term -- the contribution of a
+    # single document whose layer-2 pre-activation is -1.5e-8 (typical |z2| = 0.23), i.e. a ReLU gate that fp32 and fp64 forwards
+    # decide differently (the reference's own fp32 path flips gates too: its 8.0e-4).  So the deviation is asserted MODULO GATE FLIPS:
+    # the rank-one gate terms e_n (x) h1_t of every borderline kept pre-activation (|z2| < 1e-6 in fp64) are removed by least squares,
+    # and what remains -- the arithmetic error proper -- must meet the 1e-5 bar.
+    W1, b1, W2, b2 = (sd[k].double() for k in ("fc1.weight", "fc1.bias", "fc2.weight", "fc2.bias"))
+    K1, K2 = k1.double().view(-1, 136), k2.double().view(-1, 136)
+    h1 = torch.relu(x.double().view(-1, 136) @ W1.T + b1) * K1 * 2
+    z2 = h1 @ W2.T + b2
+    border = ((z2.abs() < 1e-6) & (K2 > 0)).nonzero().tolist()
+    assert 0 < len(border) < 500
+    dev_m = torch.from_numpy(got["fc2.weight"]).double() - torch.from_numpy(rg["fc2.weight"]).double()
+    A = torch.zeros(136 * 136, len(border), dtype=torch.float64)
+    for c, (t, n) in enumerate(border):
+        A[n * 136:(n + 1) * 136, c] = h1[t]
+    coef = torch.linalg.lstsq(A, dev_m.flatten()[:, None]).solution
+    res = dev_m.flatten() - (A @ coef)[:, 0]
+    top = float(np.abs(rg["fc2.weight"]).max())
+    e_flip = float(res.abs().max()) / top
+    ledger_record("bench-batch grad[fc2.weight] / max|tensor|, ReLU gate flips of borderline pre-activations removed", e_flip)
+    assert e_flip < TOL, (float(dev_m.abs().max()) / top, e_flip, len(border))
 
 
 @pytest.mark.parametrize("S", [32, 128])
