@@ -264,29 +264,32 @@ layernorm_fwd_kernel(const float *__restrict__ x, const float *__restrict__ a, c
     }
 }
 
-// d <= 128 (d % 4 == 0): 32 lanes x 4 consecutive features per token, two tokens per wave (see layernorm_bwd_v4_kernel)
+// d % 4 == 0, d <= 4 LPT: LPT lanes x 4 consecutive features per token (one 16-byte load), 64 / LPT tokens per wave.
+// LPT = 32: d <= 128 (two tokens per wave); LPT = 64: d <= 256 (the reference's default d_model = 136).  See layernorm_bwd_v4_kernel.
+template <int LPT>
 __global__ void __launch_bounds__(kLnThreads)
 layernorm_fwd_v4_kernel(const float *__restrict__ x, const float *__restrict__ a, const float *__restrict__ b, long long T, int d,
                         float eps, int standard, bf16_t *__restrict__ yb, float *__restrict__ yf) {
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, half = lane >> 5, f0 = 4 * (lane & 31);
+    constexpr int TPW = 64 / LPT;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, half = lane / LPT, f0 = 4 * (lane % LPT);
     const bool in = f0 < d;
     f32x4 av = {0.f, 0.f, 0.f, 0.f}, bv = av;
     if (in) {
         av = *reinterpret_cast<const f32x4 *>(a + f0);
         bv = *reinterpret_cast<const f32x4 *>(b + f0);
     }
-    for (long long t = ((long long)blockIdx.x * 4 + w) * 2 + half; t < T; t += (long long)gridDim.x * 8) {
+    for (long long t = ((long long)blockIdx.x * 4 + w) * TPW + half; t < T; t += (long long)gridDim.x * 4 * TPW) {
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
         if (in) v = *reinterpret_cast<const f32x4 *>(x + t * d + f0);
         float s = (v[0] + v[1]) + (v[2] + v[3]);
 #pragma unroll
-        for (int o = 16; o >= 1; o >>= 1) s += __shfl_xor(s, o, 64);
+        for (int o = LPT / 2; o >= 1; o >>= 1) s += __shfl_xor(s, o, 64);
         const float mean = s / (float)d;
         f32x4 c = v - mean;
         if (!in) c = f32x4{0.f, 0.f, 0.f, 0.f};
         float q = (c[0] * c[0] + c[1] * c[1]) + (c[2] * c[2] + c[3] * c[3]);
 #pragma unroll
-        for (int o = 16; o >= 1; o >>= 1) q += __shfl_xor(q, o, 64);
+        for (int o = LPT / 2; o >= 1; o >>= 1) q += __shfl_xor(q, o, 64);
         const float r = standard ? 1.f / sqrtf(q / (float)d + eps) : 1.f / (sqrtf(q / (float)(d - 1)) + eps);
         if (in) {
             const f32x4 y = av * c * r + bv;
@@ -365,32 +368,35 @@ layernorm_bwd_kernel(const float *__restrict__ x, const float *__restrict__ a, c
     block_cols_out(db, d, red, partials + (long long)blockIdx.x * 2 * d + d);
 }
 
-// LayerNorm backward for d <= 128 (d % 4 == 0): a token is 32 lanes x 4 consecutive features (one 16-byte load per
-// array), a wave works on two tokens at once -- twice the bytes in flight of the general kernel above.
+// LayerNorm backward for d % 4 == 0, d <= 4 LPT: a token is LPT lanes x 4 consecutive features (one 16-byte load per
+// array), a wave works on 64 / LPT tokens at once (LPT = 32: d <= 128, two tokens -- twice the bytes in flight of the general kernel
+// above; LPT = 64: d <= 256).
+template <int LPT>
 __global__ void __launch_bounds__(kLnThreads)
 layernorm_bwd_v4_kernel(const float *__restrict__ x, const float *__restrict__ a, const float *__restrict__ dy, long long T, int d,
                         float eps, int standard, float *__restrict__ dxo, float *__restrict__ partials) {
-    __shared__ float red[8 * 128 * 2];        // [4 waves x 2 token slots][da | db][128]
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, half = lane >> 5, l = lane & 31, f0 = 4 * l;
+    constexpr int TPW = 64 / LPT, WD = 4 * LPT;      // token slots per wave, features per slot
+    __shared__ float red[4 * TPW * WD * 2];   // [4 waves x TPW token slots][da | db][WD]
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, half = lane / LPT, l = lane % LPT, f0 = 4 * l;
     const bool in = f0 < d;
     f32x4 av = {0.f, 0.f, 0.f, 0.f}, da = av, db = av;
     if (in) av = *reinterpret_cast<const f32x4 *>(a + f0);
-    for (long long t = ((long long)blockIdx.x * 4 + w) * 2 + half; t < T; t += (long long)gridDim.x * 8) {
+    for (long long t = ((long long)blockIdx.x * 4 + w) * TPW + half; t < T; t += (long long)gridDim.x * 4 * TPW) {
         f32x4 v = {0.f, 0.f, 0.f, 0.f}, g = v;
         if (in) {
             v = *reinterpret_cast<const f32x4 *>(x + t * d + f0);
             g = *reinterpret_cast<const f32x4 *>(dy + t * d + f0);
         }
-        // statistics over the token's 32 lanes (xor 1..16 stays inside the half wave)
+        // statistics over the token's LPT lanes (the xor distances stay inside the token's lane group)
         float s = (v[0] + v[1]) + (v[2] + v[3]);
 #pragma unroll
-        for (int o = 16; o >= 1; o >>= 1) s += __shfl_xor(s, o, 64);
+        for (int o = LPT / 2; o >= 1; o >>= 1) s += __shfl_xor(s, o, 64);
         const float mean = s / (float)d;
         f32x4 c = v - mean;
         if (!in) c = f32x4{0.f, 0.f, 0.f, 0.f};
         float q = (c[0] * c[0] + c[1] * c[1]) + (c[2] * c[2] + c[3] * c[3]);
 #pragma unroll
-        for (int o = 16; o >= 1; o >>= 1) q += __shfl_xor(q, o, 64);
+        for (int o = LPT / 2; o >= 1; o >>= 1) q += __shfl_xor(q, o, 64);
         float sigma, r;
         if (standard) { sigma = sqrtf(q / (float)d + eps); r = 1.f / sigma; }
         else { sigma = sqrtf(q / (float)(d - 1)); r = 1.f / (sigma + eps); }
@@ -399,7 +405,7 @@ layernorm_bwd_v4_kernel(const float *__restrict__ x, const float *__restrict__ a
         g *= av;
         float sg = (g[0] + g[1]) + (g[2] + g[3]), sgc = (g[0] * c[0] + g[1] * c[1]) + (g[2] * c[2] + g[3] * c[3]);
 #pragma unroll
-        for (int o = 16; o >= 1; o >>= 1) {
+        for (int o = LPT / 2; o >= 1; o >>= 1) {
             sg += __shfl_xor(sg, o, 64);
             sgc += __shfl_xor(sgc, o, 64);
         }
@@ -411,19 +417,19 @@ layernorm_bwd_v4_kernel(const float *__restrict__ x, const float *__restrict__ a
             *reinterpret_cast<f32x4 *>(dxo + t * d + f0) = o4;
         }
     }
-    // column sums: 8 (wave, token slot) partial rows -> fixed-order sum
-    float *row = red + (2 * w + half) * 256;
+    // column sums: 4 TPW (wave, token slot) partial rows -> fixed-order sum
+    float *row = red + (TPW * w + half) * 2 * WD;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         row[f0 + k] = da[k];
-        row[128 + f0 + k] = db[k];
+        row[WD + f0 + k] = db[k];
     }
     __syncthreads();
     for (int f = threadIdx.x; f < 2 * d; f += kLnThreads) {
-        const int col = f < d ? f : 128 + (f - d);
+        const int col = f < d ? f : WD + (f - d);
         float sacc = 0.f;
 #pragma unroll
-        for (int k = 0; k < 8; ++k) sacc += red[k * 256 + col];
+        for (int k = 0; k < 4 * TPW; ++k) sacc += red[k * 2 * WD + col];
         partials[(long long)blockIdx.x * 2 * d + f] = sacc;
     }
 }
@@ -2278,8 +2284,12 @@ int ltr_enc_layernorm_fwd(const float *x, const float *a, const float *b, int64_
     if (!x || !a || !b || (!y_bf16 && !y_f32)) return LTR_ERR_NULL;
     if (T < 0 || d < 2 || d > 64 * kLnMax) return LTR_ERR_SHAPE;
     if (T == 0) return LTR_OK;
-    if (d <= 128 && d % 4 == 0 && !(((uintptr_t)x | (uintptr_t)a | (uintptr_t)b | (uintptr_t)y_f32) & 15u) && !((uintptr_t)y_bf16 & 7u))
-        hipLaunchKernelGGL(layernorm_fwd_v4_kernel, dim3(elt_grid(T, 8, 256 * 16)), dim3(kLnThreads), 0, (hipStream_t)stream, x, a, b,
+    const bool v4 = d % 4 == 0 && !(((uintptr_t)x | (uintptr_t)a | (uintptr_t)b | (uintptr_t)y_f32) & 15u) && !((uintptr_t)y_bf16 & 7u);
+    if (v4 && d <= 128)
+        hipLaunchKernelGGL(layernorm_fwd_v4_kernel<32>, dim3(elt_grid(T, 8, 256 * 16)), dim3(kLnThreads), 0, (hipStream_t)stream, x, a, b,
+                           (long long)T, d, eps, standard, y_bf16, y_f32);
+    else if (v4 && d <= 256)
+        hipLaunchKernelGGL(layernorm_fwd_v4_kernel<64>, dim3(elt_grid(T, 4, 256 * 16)), dim3(kLnThreads), 0, (hipStream_t)stream, x, a, b,
                            (long long)T, d, eps, standard, y_bf16, y_f32);
     else
         hipLaunchKernelGGL(layernorm_fwd_kernel, dim3(elt_grid(T, 4)), dim3(kLnThreads), 0, (hipStream_t)stream, x, a, b, (long long)T, d,
@@ -2291,8 +2301,12 @@ int ltr_enc_layernorm_bwd(const float *x, const float *a, const float *dy, int64
                           float *dx, float *partials, int nblk, void *stream) {
     if (!x || !a || !dy || !dx || !partials) return LTR_ERR_NULL;
     if (T < 0 || d < 2 || d > 64 * kLnMax || nblk < 1 || nblk > 65535) return LTR_ERR_SHAPE;
-    if (d <= 128 && d % 4 == 0 && !(((uintptr_t)x | (uintptr_t)dy | (uintptr_t)dx | (uintptr_t)a) & 15u))
-        hipLaunchKernelGGL(layernorm_bwd_v4_kernel, dim3(nblk), dim3(kLnThreads), 0, (hipStream_t)stream, x, a, dy, (long long)T, d, eps,
+    const bool v4 = d % 4 == 0 && !(((uintptr_t)x | (uintptr_t)dy | (uintptr_t)dx | (uintptr_t)a) & 15u);
+    if (v4 && d <= 128)
+        hipLaunchKernelGGL(layernorm_bwd_v4_kernel<32>, dim3(nblk), dim3(kLnThreads), 0, (hipStream_t)stream, x, a, dy, (long long)T, d, eps,
+                           standard, dx, partials);
+    else if (v4 && d <= 256)
+        hipLaunchKernelGGL(layernorm_bwd_v4_kernel<64>, dim3(nblk), dim3(kLnThreads), 0, (hipStream_t)stream, x, a, dy, (long long)T, d, eps,
                            standard, dx, partials);
     else
         hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(nblk), dim3(kLnThreads), 0, (hipStream_t)stream, x, a, dy, (long long)T, d, eps,

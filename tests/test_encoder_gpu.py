@@ -152,7 +152,7 @@ def _ln_ref(x, a, b, eps, standard):
     return a * (x - x.mean(-1, keepdim=True)) / (x.std(-1, keepdim=True) + eps) + b
 
 
-@pytest.mark.parametrize("d", [16, 128, 136, 264, 512])
+@pytest.mark.parametrize("d", [16, 100, 128, 136, 200, 256, 264, 512])
 @pytest.mark.parametrize("standard", [0, 1])
 def test_layernorm_fwd_bwd(enc, d, standard):
     torch.manual_seed(d)
