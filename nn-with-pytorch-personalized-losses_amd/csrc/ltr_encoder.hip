@@ -1597,11 +1597,32 @@ __device__ __forceinline__ u32x4 load8(const bf16_t *row, int d0, int dk, bool v
         if (d0 + 8 <= dk) r = *reinterpret_cast<const u32x4 *>(row + d0);
         return r;
     }
-    unsigned short e[8];
+    // head slices that are not multiples of 16 bytes (dk = 17: 34-byte slices): the (at most two) ALIGNED 16-byte chunks that hold
+    // the valid elements, funnel-shifted into place.  Token rows are multiples of 16 bytes (d % 8 == 0) and d0 is a multiple of 8, so
+    // the misalignment is the same for every lane of the workgroup (scalar); a chunk is only touched if it holds a valid element, so
+    // nothing outside the row is read.  (Was: eight guarded 2-byte loads per lane.)
+    const int nvalid = dk - d0 < 8 ? dk - d0 : 8;
+    if (nvalid <= 0) return r;
+    const uintptr_t addr = reinterpret_cast<uintptr_t>(row + d0);
+    const unsigned sh = (unsigned)__builtin_amdgcn_readfirstlane((int)(addr & 15u));
+    const u32x4 *q = reinterpret_cast<const u32x4 *>(addr - (addr & 15u));
+    const u32x4 c0 = q[0];
+    u32x4 c1 = {0u, 0u, 0u, 0u};
+    if ((int)sh + 2 * nvalid > 16) c1 = q[1];
+    const unsigned bs = sh & 3u;                  // 0 or 2 bytes (bf16 elements)
+    switch (sh >> 2) {                            // scalar branch
+        case 0: r = u32x4{__builtin_amdgcn_alignbyte(c0[1], c0[0], bs), __builtin_amdgcn_alignbyte(c0[2], c0[1], bs),
+                          __builtin_amdgcn_alignbyte(c0[3], c0[2], bs), __builtin_amdgcn_alignbyte(c1[0], c0[3], bs)}; break;
+        case 1: r = u32x4{__builtin_amdgcn_alignbyte(c0[2], c0[1], bs), __builtin_amdgcn_alignbyte(c0[3], c0[2], bs),
+                          __builtin_amdgcn_alignbyte(c1[0], c0[3], bs), __builtin_amdgcn_alignbyte(c1[1], c1[0], bs)}; break;
+        case 2: r = u32x4{__builtin_amdgcn_alignbyte(c0[3], c0[2], bs), __builtin_amdgcn_alignbyte(c1[0], c0[3], bs),
+                          __builtin_amdgcn_alignbyte(c1[1], c1[0], bs), __builtin_amdgcn_alignbyte(c1[2], c1[1], bs)}; break;
+        default: r = u32x4{__builtin_amdgcn_alignbyte(c1[0], c0[3], bs), __builtin_amdgcn_alignbyte(c1[1], c1[0], bs),
+                           __builtin_amdgcn_alignbyte(c1[2], c1[1], bs), __builtin_amdgcn_alignbyte(c1[3], c1[2], bs)}; break;
+    }
 #pragma unroll
-    for (int x = 0; x < 8; ++x) e[x] = d0 + x < dk ? row[d0 + x] : (unsigned short)0;
-    return u32x4{(unsigned)e[0] | ((unsigned)e[1] << 16), (unsigned)e[2] | ((unsigned)e[3] << 16),
-                 (unsigned)e[4] | ((unsigned)e[5] << 16), (unsigned)e[6] | ((unsigned)e[7] << 16)};
+    for (int jj = 0; jj < 4; ++jj) r[jj] &= nvalid >= 2 * jj + 2 ? 0xffffffffu : (nvalid == 2 * jj + 1 ? 0x0000ffffu : 0u);
+    return r;
 }
 // 4 consecutive head features d0..d0+3 of an accumulator -> bf16 row (guarded)
 __device__ __forceinline__ void store4(bf16_t *row, int d0, int dk, bool vec, const f32x4 &v) {

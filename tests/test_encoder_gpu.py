@@ -274,9 +274,11 @@ def test_attention_fwd_bwd(enc, B, S, h, dk, p):
 
 
 @pytest.mark.parametrize("B,S,h,dk,p", [(2, 12, 4, 8, 0.0), (3, 40, 2, 16, 0.1), (2, 100, 8, 16, 0.1), (9, 128, 8, 16, 0.1), (2, 200, 4, 12, 0.0),
-                                        (2, 256, 8, 16, 0.2), (10, 256, 8, 16, 0.1), (3, 250, 8, 16, 0.0)])
+                                        (2, 256, 8, 16, 0.2), (10, 256, 8, 16, 0.1), (3, 250, 8, 16, 0.0),
+                                        (2, 256, 8, 17, 0.1), (9, 256, 2, 32, 0.1), (3, 100, 4, 24, 0.1), (5, 128, 8, 17, 0.1), (2, 250, 2, 32, 0.0)])
 def test_attention_key_major_backward(enc, B, S, h, dk, p):
-    """ltr_enc_attention_fwd_lse / _bwd_lse (every probability evaluated once, key-major; dk <= 16, S <= 256): against the
+    """ltr_enc_attention_fwd_lse / _bwd_lse (every probability evaluated once, key-major, for dk <= 16 and S <= 256; the dk 17 / 24 / 32
+    cases take the two-phase kernel behind the same entry and exercise the funnel-shifted loads of unaligned head slices): against the
     fp64 reference at the bf16 bar of test_attention_fwd_bwd, against the two-phase kernel on the same inputs (same rounding
     points; the only difference is exp2(c2 s - lse2) for exp2(c2 s - max) / sum in the dQ contraction), bit-reproducible,
     and lse2 itself against log2-sum-exp of the reference scores."""

@@ -88,6 +88,15 @@ def main():
                                                                                                 _ptr(lse), _stream()), "f")), att_f, T * d * 8)
         rec(f"attention bwd key-major (lse) p={p}", timeit(lambda: check(lib().ltr_enc_attention_bwd_lse(
             _ptr(qkv), _ptr(ctx), _ptr(dy), _ptr(lse), _ptr(mask), B, S, h, dk, p, 1, 0, _ptr(dqkv), _stream()), "b")), att_f * 2.5, T * d * 16)
+    # the reference's default geometry: d_model 136 = 8 heads x 17
+    d17, dk17 = 136, 17
+    qkv17, ctx17, dq17, dy17 = bf(T, 3 * d17), torch.empty(T, d17, dtype=torch.int16, device=dev), torch.empty(T, 3 * d17, dtype=torch.int16, device=dev), bf(T, d17)
+    rec("attention fwd +lse dk=17 p=0.1", timeit(lambda: check(lib().ltr_enc_attention_fwd_lse(_ptr(qkv17), _ptr(mask), B, S, h, dk17, 0.1, 1, 0, _ptr(ctx17),
+                                                                                                  _ptr(lse), _stream()), "f")), 2 * 2 * B * h * S * S * dk17, T * d17 * 8)
+    rec("attention bwd key-major (lse) dk=17 p=0.1", timeit(lambda: check(lib().ltr_enc_attention_bwd_lse(
+        _ptr(qkv17), _ptr(ctx17), _ptr(dy17), _ptr(lse), _ptr(mask), B, S, h, dk17, 0.1, 1, 0, _ptr(dq17), _stream()), "b")), 5 * 2 * B * h * S * S * dk17, T * d17 * 16)
+    rec("attention bwd two-phase dk=17 p=0.1", timeit(lambda: check(lib().ltr_enc_attention_bwd(
+        _ptr(qkv17), _ptr(ctx17), _ptr(dy17), _ptr(mask), B, S, h, dk17, 0.1, 1, 0, _ptr(dq17), _stream()), "b")), 7 * 2 * B * h * S * S * dk17, T * d17 * 16)
     xf, a_, b_ = torch.randn(T, d, device=dev), torch.ones(d, device=dev), torch.zeros(d, device=dev)
     rec("layernorm fwd (-> bf16)", timeit(lambda: E.layernorm_fwd(xf, a_, b_, T, d, 1e-6, 0)), 0, T * d * 6)
     dxa = torch.zeros(T, d, device=dev)
