@@ -123,6 +123,18 @@ int ltr_risk_fwd_bwd(const float *mat, int Q, int n_systems, int col, float alph
 int ltr_trisk_fwd_bwd(const float *model, const float *baseline, int Q, float alpha, float *value, float *dmodel,
                       float *dbaseline, void *stream);
 
+/* The [queries x systems] effectiveness matrix of the six risk-sensitive losses in ONE launch (losses/riskLosses/riskLosses.py:8-49,
+ * :63-117, :128-169, :183-236, :247-276, :294-330), mat [B][1 + n_rest + (ideal != 0)] row-major: column 0 the model, then the
+ * baseline rankers, optionally the ideal ranking (the reference vector itself); and jac [B][S] = d mat[b][0] / d x0[b][j] (NULL = not
+ * wanted) -- the only gradient the losses need.
+ *   mode 0 (Listnet type): ref = y_true, x0 = y_predicted, rest = y_baselines [B][S][n_rest]; each vector is soft-maxed over the slate
+ *     (:10-12), then lt 1: sum (t p - t^2)^2, 2: cosine(t, p), 3: (sum t p - sum t^2)^2.
+ *   mode 1 (Lambda type): ref, x0, rest [n_rest][B][S] are lambdaMask column sums (ltr_lambda_colsum_fwd), taken as they are;
+ *     lt 1: sum (x - t)^2, 2: cosine(t, x), 3: (sum x - sum t)^2.
+ * The caller applies the `-mat + max(mat)` flip of lt 1 / 3 (:47-49; a whole-matrix maximum).  S <= 2048. */
+int ltr_risk_matrix_fwd(const float *ref, const float *x0, const float *rest, int B, int S, int n_rest, int mode, int lt, int ideal,
+                        float *mat, float *jac, void *stream);
+
 /* ---- mNdcg / ndcg / dcg / torchNdcg                                            utils/metrics.py:48-104
  * Per-query NDCG@k on the device (the reference loops over queries in Python after every epoch,
  * main_batch_execution.py:173-200).  y_true, y_score: [Q][S] fp32.  k is clamped to S (:54-55).

@@ -139,6 +139,120 @@ inline int status() {
     return e == hipSuccess ? LTR_OK : (int)e;
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// The [queries x systems] effectiveness matrix of the risk-sensitive losses, one workgroup per query, one launch for all systems
+// (riskLosses.py:8-49 / :128-169 / :247-276 Listnet type, :63-117 / :183-236 / :294-330 Lambda type) -- and d mat[q][0] / d (the
+// model's input), the only gradient the losses need (column 0 is the model; baselines and the ideal ranking are constants).
+//   mode 0 (Listnet type): ref = labels, x0 = the model's scores, rest = baseline scores [B][S][nr]; every vector is soft-maxed over
+//     the slate first (:10-12);  lt 1: sum_j (t p - t^2)^2   lt 2: cos(t, p)   lt 3: (sum t p - sum t^2)^2        (:16-46)
+//   mode 1 (Lambda type): ref / x0 / rest [nr][B][S] are the lambdaMask column sums, used as they are;
+//     lt 1: sum_j (x - t)^2   lt 2: cos(t, x)   lt 3: (sum x - sum t)^2                                          (:71-104)
+//   ideal != 0 appends the column of the reference vector itself.
+// fp32 elementwise arithmetic, fp64 sums, fixed-order reductions.  The cosine follows ATen: w12 / sqrt(max(w1 w2, eps^2)), eps 1e-8.
+constexpr int kMatThreads = 256;
+constexpr int kMatMaxS = 2048;
+
+__device__ __forceinline__ double mat_block_sum(double v, double *red) {
+    v = wave_allsum_f64(v);
+    __syncthreads();
+    if ((threadIdx.x & (LTR_WAVE - 1)) == 0) red[threadIdx.x / LTR_WAVE] = v;
+    __syncthreads();
+    double s = 0.0;
+    for (int w = 0; w < kMatThreads / LTR_WAVE; ++w) s += red[w];
+    return s;
+}
+__device__ __forceinline__ float mat_block_max(float v, double *red) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, LTR_WAVE));
+    __syncthreads();
+    if ((threadIdx.x & (LTR_WAVE - 1)) == 0) red[threadIdx.x / LTR_WAVE] = (double)v;
+    __syncthreads();
+    float m = -INFINITY;
+    for (int w = 0; w < kMatThreads / LTR_WAVE; ++w) m = fmaxf(m, (float)red[w]);
+    return m;
+}
+// in place: v[0..S) -> softmax(v) (torch: exp(x - max) / sum)
+__device__ __forceinline__ void mat_softmax(float *v, int S, double *red) {
+    float m = -INFINITY;
+    for (int j = threadIdx.x; j < S; j += kMatThreads) m = fmaxf(m, v[j]);
+    m = mat_block_max(m, red);
+    double z = 0.0;
+    for (int j = threadIdx.x; j < S; j += kMatThreads) {
+        const float e = expf(v[j] - m);
+        v[j] = e;
+        z += (double)e;
+    }
+    const float inv = (float)(1.0 / mat_block_sum(z, red));
+    for (int j = threadIdx.x; j < S; j += kMatThreads) v[j] *= inv;
+    __syncthreads();
+}
+
+__global__ void __launch_bounds__(kMatThreads)
+risk_matrix_kernel(const float *__restrict__ ref, const float *__restrict__ x0, const float *__restrict__ rest, int B, int S, int nr,
+                   int mode, int lt, int ideal, float *__restrict__ mat, float *__restrict__ jac) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    __shared__ double red[kMatThreads / LTR_WAVE];
+    float *t = smem, *x = smem + S;
+    const int b = blockIdx.x, tid = threadIdx.x, nsys = 1 + nr + (ideal ? 1 : 0);
+    for (int j = tid; j < S; j += kMatThreads) t[j] = ref[(size_t)b * S + j];
+    __syncthreads();
+    if (mode == 0) mat_softmax(t, S, red);
+    double nt_a = 0.0, st_a = 0.0;
+    for (int j = tid; j < S; j += kMatThreads) {
+        nt_a += (double)t[j] * t[j];
+        st_a += (double)t[j];
+    }
+    const double nt = mat_block_sum(nt_a, red), st = mat_block_sum(st_a, red);
+    for (int sys = 0; sys < nsys; ++sys) {
+        const bool is_ideal = ideal && sys == nsys - 1;
+        __syncthreads();
+        for (int j = tid; j < S; j += kMatThreads) {
+            float v;
+            if (is_ideal) v = t[j];
+            else if (sys == 0) v = x0[(size_t)b * S + j];
+            else v = mode == 0 ? rest[((size_t)b * S + j) * nr + (sys - 1)] : rest[((size_t)(sys - 1) * B + b) * S + j];
+            x[j] = v;
+        }
+        __syncthreads();
+        if (mode == 0 && !is_ideal) mat_softmax(x, S, red);
+        double a_a = 0.0, nx_a = 0.0, c_a = 0.0, sx_a = 0.0;
+        for (int j = tid; j < S; j += kMatThreads) {
+            const float tj = t[j], xj = x[j];
+            a_a += (double)tj * xj;
+            nx_a += (double)xj * xj;
+            sx_a += (double)xj;
+            const float df = mode == 0 ? tj * xj - tj * tj : xj - tj;
+            c_a += (double)df * df;
+        }
+        const double a = mat_block_sum(a_a, red), nx = mat_block_sum(nx_a, red), c = mat_block_sum(c_a, red), sx = mat_block_sum(sx_a, red);
+        const double den2 = nt * nx > 1e-16 ? nt * nx : 1e-16, den = sqrt(den2);
+        double m;
+        if (lt == 1) m = c;
+        else if (lt == 2) m = a / den;
+        else m = mode == 0 ? (a - nt) * (a - nt) : (sx - st) * (sx - st);
+        if (tid == 0) mat[(size_t)b * nsys + sys] = (float)m;
+        if (sys == 0 && jac) {
+            // g_j = d m / d x_j; mode 0: x = softmax(s): d m / d s_j = x_j (g_j - sum_k x_k g_k)
+            const bool clamped = !(nt * nx > 1e-16);
+            auto grad = [&](int j) -> double {
+                const double tj = t[j], xj = x[j];
+                if (lt == 1) return mode == 0 ? 2.0 * tj * (tj * xj - tj * tj) : 2.0 * (xj - tj);
+                if (lt == 2) return clamped ? tj / den : tj / den - m * xj / nx;
+                return mode == 0 ? 2.0 * (a - nt) * tj : 2.0 * (sx - st);
+            };
+            if (mode == 0) {
+                double dot_a = 0.0;
+                for (int j = tid; j < S; j += kMatThreads) dot_a += (double)x[j] * grad(j);
+                const double dot = mat_block_sum(dot_a, red);
+                for (int j = tid; j < S; j += kMatThreads) jac[(size_t)b * S + j] = (float)((double)x[j] * (grad(j) - dot));
+            } else {
+                for (int j = tid; j < S; j += kMatThreads) jac[(size_t)b * S + j] = (float)grad(j);
+            }
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -163,6 +277,18 @@ int ltr_trisk_fwd_bwd(const float *model, const float *baseline, int Q, float al
     hipLaunchKernelGGL(trisk_kernel, dim3(1), dim3(kRiskThreads), 0, (hipStream_t)stream, model, baseline, Q, alpha, value,
                        dmodel, dbaseline);
     return status();
+}
+
+int ltr_risk_matrix_fwd(const float *ref, const float *x0, const float *rest, int B, int S, int n_rest, int mode, int lt, int ideal,
+                        float *mat, float *jac, void *stream) {
+    if (!ref || !x0 || !mat || (n_rest > 0 && !rest)) return LTR_ERR_NULL;
+    if (B < 0 || S < 1 || S > kMatMaxS || n_rest < 0 || n_rest > 64) return LTR_ERR_SHAPE;
+    if ((mode != 0 && mode != 1) || lt < 1 || lt > 3) return LTR_ERR_PARAM;
+    if (B == 0) return LTR_OK;
+    hipLaunchKernelGGL(risk_matrix_kernel, dim3(B), dim3(kMatThreads), (size_t)2 * S * sizeof(float), (hipStream_t)stream, ref, x0, rest, B,
+                       S, n_rest, mode, lt, ideal ? 1 : 0, mat, jac);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? LTR_OK : (int)e;
 }
 
 }  // extern "C"

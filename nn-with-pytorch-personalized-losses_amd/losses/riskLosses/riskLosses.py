@@ -6,8 +6,10 @@ Each loss builds a [queries, systems] effectiveness matrix -- column 0 the model
 optionally the ideal ranking -- from row-softmaxed labels / predictions / baseline scores, and hands it to a risk
 function.  On the MI355X: the pair-matrix column sums of the Lambda variants come from `ltr_lambda_colsum_*`
 (no [B,S,S] tensor is ever written), the risk reductions from `ltr_risk_fwd_bwd` / `ltr_trisk_fwd_bwd`
-(forward + analytic gradient per launch); the [B,S]-sized glue in between (softmax, squares, cosine) is plain
-device tensor algebra.  Device tensors only.
+(forward + analytic gradient per launch), and -- for the regular shapes of the geoRisk / zRisk losses -- the whole
+[queries, systems] matrix from ONE launch (`ltr_risk_matrix_fwd`: softmaxes, transformation, every system, and the
+gradient of the model's column).  Irregular shapes (a squeezed single baseline, B = 1, ...) and the tRisk pair walk the
+tensor-algebra path, which reproduces the reference's squeeze quirks literally.  Device tensors only.
 """
 import torch
 import torch.nn.functional as F
@@ -55,6 +57,45 @@ def _effectiveness(ref, sys3, lt):
     return (torch.sum(sys3, dim=2) - torch.sum(ref, dim=1)) ** 2
 
 
+_FUSED_MAX_SLATE = 2048
+
+
+def _regular(y_predicted, y_true, y_baselines):
+    """The shapes the one-launch matrix kernel takes (anything else walks the tensor-algebra path below, which reproduces the
+    reference's squeeze quirks literally): fp32 [B, S] or [B, S, 1] scores / labels with B, S > 1, baselines None or [B, S, n >= 2]."""
+    def two_d(t):
+        if t.dim() == 3 and t.shape[2] == 1:
+            t = t[:, :, 0]
+        ok = t.dim() == 2 and t.shape[0] > 1 and 1 < t.shape[1] <= _FUSED_MAX_SLATE and t.dtype == torch.float32
+        return t if ok else None
+    yp, yt = two_d(y_predicted), two_d(y_true)
+    if yp is None or yt is None or yp.shape != yt.shape:
+        return None
+    yb = y_baselines
+    if yb is not None and (yb.dim() != 3 or tuple(yb.shape[:2]) != tuple(yp.shape) or yb.shape[2] < 2 or yb.shape[2] > 64
+                           or yb.dtype != torch.float32):
+        return None
+    return yp, yt, yb
+
+
+def _flip(mat, lt):
+    # larger distance = worse: flip so that larger = better (:47-49)
+    return -mat + torch.max(mat) if lt in (1, 3) else mat
+
+
+def _listnet_mat_fused(y_predicted, y_true, y_baselines, lt, add_ideal):
+    """Queries x systems matrix of the Listnet-type losses in one launch (softmaxes, transformation, every system); None when
+    the shapes are not the regular ones."""
+    require_device(y_predicted, y_true)
+    reg = _regular(y_predicted, y_true, y_baselines)
+    if reg is None:
+        return None
+    if lt not in (1, 2, 3):
+        _unbound()
+    yp, yt, yb = reg
+    return _flip(_risk.risk_matrix(yt, yp, yb, 0, lt, add_ideal == 2), lt)
+
+
 def _listnet_mat(p_true, p_pred, p_base, lt, add_ideal):
     """Queries x systems matrix of the Listnet-type losses (:16-49, :136-169)."""
     if lt not in (1, 2, 3):
@@ -85,8 +126,14 @@ def _lambda_mat(p_true, p_pred, p_base, lt, add_ideal, scheme, ideal_is_ones):
             stacked = p_base.permute(2, 0, 1).reshape(nb * B, S).contiguous()
             cb = _risk.lambda_colsum(stacked, p_true.repeat(nb, 1), scheme).view(nb, B, S)
     cp = _risk.lambda_colsum(p_pred, p_true, scheme)
-    parts = [cp.unsqueeze(0)] + ([cb] if cb is not None else [])
     ones_col = add_ideal == 2 and lt == 2 and ideal_is_ones
+    if tt.dtype == torch.float32 and cp.dtype == torch.float32 and 1 < S <= _FUSED_MAX_SLATE and (cb is None or cb.shape[0] <= 64):
+        # one launch for every system's effectiveness (+ d mat[:, 0] / d cp for the backward)
+        mat = _risk.risk_matrix(tt, cp, None if cb is None else cb.contiguous(), 1, lt, add_ideal == 2 and not ones_col)
+        if ones_col:
+            mat = torch.cat([mat, torch.ones((B, 1), dtype=mat.dtype, device=mat.device)], 1)        # :106
+        return -mat + torch.max(mat) if lt == 1 else mat
+    parts = [cp.unsqueeze(0)] + ([cb] if cb is not None else [])
     if add_ideal == 2 and not ones_col:
         parts.append(tt.unsqueeze(0))
     mat = _effectiveness(tt, parts[0] if len(parts) == 1 else torch.cat(parts, 0), lt)
@@ -115,8 +162,10 @@ def _by_strategy(risk, mat, alpha, return_strategy, factor):
 
 def geoRiskListnetLoss(y_predicted, y_true, y_baselines=None, alpha=5, listnet_transformation=1, return_strategy=1,
                        negative=1, add_ideal_ranking_to_mat=1):
-    p_true, p_pred, p_base = _probs(y_predicted, y_true, y_baselines)
-    mat = _listnet_mat(p_true, p_pred, p_base, listnet_transformation, add_ideal_ranking_to_mat)
+    mat = _listnet_mat_fused(y_predicted, y_true, y_baselines, listnet_transformation, add_ideal_ranking_to_mat)
+    if mat is None:
+        p_true, p_pred, p_base = _probs(y_predicted, y_true, y_baselines)
+        mat = _listnet_mat(p_true, p_pred, p_base, listnet_transformation, add_ideal_ranking_to_mat)
     return _by_strategy(geoRisk, mat, alpha, return_strategy, _factor(negative, mat))
 
 
@@ -129,8 +178,10 @@ def geoRiskLambdaLoss(y_predicted, y_true, y_baselines=None, alpha=5, listnet_tr
 
 def zRiskListnetLoss(y_predicted, y_true, y_baselines=None, alpha=5, listnet_transformation=1, return_strategy=1,
                      negative=1, add_ideal_ranking_to_mat=1):
-    p_true, p_pred, p_base = _probs(y_predicted, y_true, y_baselines)
-    mat = _listnet_mat(p_true, p_pred, p_base, listnet_transformation, add_ideal_ranking_to_mat)
+    mat = _listnet_mat_fused(y_predicted, y_true, y_baselines, listnet_transformation, add_ideal_ranking_to_mat)
+    if mat is None:
+        p_true, p_pred, p_base = _probs(y_predicted, y_true, y_baselines)
+        mat = _listnet_mat(p_true, p_pred, p_base, listnet_transformation, add_ideal_ranking_to_mat)
     factor = _factor(negative, mat)
     # the reference's operator precedence (:176-178): `factor` multiplies only the first term of strategy 2 and
     # the squared difference of strategy 3

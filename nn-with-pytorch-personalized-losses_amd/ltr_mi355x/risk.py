@@ -94,6 +94,38 @@ class LambdaColsum(torch.autograd.Function):
         return (ds.to(ctx.in_dtype),) + (None,) * 8
 
 
+class RiskMatrix(torch.autograd.Function):
+    """The [queries, systems] effectiveness matrix of the risk-sensitive losses in ONE launch (riskLosses.py:8-49, :63-117) ->
+    ltr_risk_matrix_fwd: column 0 the model (`x0`, the only input that carries a gradient), then the baselines (`rest`), optionally
+    the ideal ranking.  mode 0: raw labels / scores / baselines [B, S, n], soft-maxed inside; mode 1: lambdaMask column sums, rest
+    [n, B, S].  The forward also writes d mat[:, 0] / d x0, so the backward is one multiply."""
+
+    @staticmethod
+    def forward(ctx, ref, x0, rest, mode, lt, ideal):
+        B, S = x0.shape
+        nr = 0 if rest is None else (rest.shape[2] if mode == 0 else rest.shape[0])
+        with torch.cuda.device(x0.device):
+            r, x = _f32(ref), _f32(x0)
+            rs = None if rest is None else _f32(rest)
+            mat = torch.empty((B, 1 + nr + (1 if ideal else 0)), dtype=torch.float32, device=x0.device)
+            jac = torch.empty((B, S), dtype=torch.float32, device=x0.device) if ctx.needs_input_grad[1] else None
+            check(lib().ltr_risk_matrix_fwd(_ptr(r), _ptr(x), _ptr(rs), B, S, nr, int(mode), int(lt), int(bool(ideal)), _ptr(mat), _ptr(jac),
+                                            _stream()), "ltr_risk_matrix_fwd")
+        ctx.save_for_backward(jac)
+        ctx.in_dtype = x0.dtype
+        return mat
+
+    @staticmethod
+    def backward(ctx, g):
+        (jac,) = ctx.saved_tensors
+        return None, (jac * g[:, 0:1].to(torch.float32)).to(ctx.in_dtype), None, None, None, None
+
+
+def risk_matrix(ref, x0, rest, mode, lt, ideal):
+    require_device(ref, x0)
+    return RiskMatrix.apply(ref, x0, rest, mode, lt, ideal)
+
+
 def z_risk(mat, alpha, i=0):
     require_device(mat)
     return RiskEval.apply(mat, alpha, i, RISK_Z)

@@ -126,6 +126,42 @@ def test_risk_losses_golden(case, dev):
         assert relerr(x.grad.cpu().numpy(), g.arr(case, "grad")) < bar
 
 
+@pytest.mark.parametrize("B,S,nb", [(2, 8, 2), (7, 33, 3), (100, 128, 3), (5, 600, 2), (4, 40, 0)])
+@pytest.mark.parametrize("lt", [1, 2, 3])
+@pytest.mark.parametrize("ideal", [1, 2])
+def test_fused_risk_matrix_matches_the_tensor_algebra_path(B, S, nb, lt, ideal, dev):
+    """ltr_risk_matrix_fwd (one launch: softmaxes, transformation, every system, d mat[:, 0] / d y_pred) against the [B, S]-sized
+    tensor algebra it replaces, in fp64 (`_listnet_mat` on fp64 inputs does not take the fused path), value and gradient; and the
+    Lambda-type effectiveness (mode 1) against `_effectiveness`."""
+    from losses.riskLosses import riskLosses as RL
+    from ltr_mi355x import risk as R
+    gen = torch.Generator().manual_seed(B * 1000 + S + lt)
+    yp, yt = torch.randn(B, S, generator=gen), torch.randint(0, 5, (B, S), generator=gen).float()
+    yb = torch.randn(B, S, nb, generator=gen) if nb else None
+    x = yp.to(dev).requires_grad_(True)
+    mat = RL._listnet_mat_fused(x, yt.to(dev), None if yb is None else yb.to(dev), lt, ideal)
+    assert mat is not None and mat.shape == (B, 1 + nb + (ideal == 2))
+    w = torch.randn(mat.shape, generator=gen).to(dev)
+    (mat * w).sum().backward()
+    x64 = yp.double().to(dev).requires_grad_(True)
+    pt, pp, pb = RL._probs(x64, yt.double().to(dev), None if yb is None else yb.double().to(dev))
+    ref = RL._listnet_mat(pt, pp, pb, lt, ideal)
+    (ref * w.double()).sum().backward()
+    assert relerr(mat.detach().cpu().numpy(), ref.detach().cpu().numpy()) < 2e-6
+    assert relerr(x.grad.cpu().numpy(), x64.grad.cpu().numpy()) < 1e-5
+    if lt < 3:                                                   # mode 1: vectors taken as they are (the Lambda losses have no lt 3)
+        tt, rest = torch.rand(B, S, generator=gen).to(dev), (torch.rand(nb, B, S, generator=gen).to(dev) if nb else None)
+        c = torch.rand(B, S, generator=gen).to(dev).requires_grad_(True)
+        m1 = R.risk_matrix(tt, c, rest, 1, lt, ideal == 2)
+        (m1 * w).sum().backward()
+        c64 = c.detach().double().requires_grad_(True)
+        parts = [c64.unsqueeze(0)] + ([rest.double()] if rest is not None else []) + ([tt.double().unsqueeze(0)] if ideal == 2 else [])
+        r1 = RL._effectiveness(tt.double(), torch.cat(parts, 0), lt).t()
+        (r1 * w.double()).sum().backward()
+        assert relerr(m1.detach().cpu().numpy(), r1.detach().cpu().numpy()) < 2e-6
+        assert relerr(c.grad.cpu().numpy(), c64.grad.cpu().numpy()) < 1e-5
+
+
 def test_risk_loss_errors_and_larger_batch(dev):
     from losses.riskLosses import riskLosses as RL
     gen = torch.Generator().manual_seed(5)

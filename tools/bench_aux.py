@@ -68,6 +68,27 @@ def main():
         rec["slates_per_s_gpu"] = round(B / rec["gpu_ms"] * 1e3)
         print(json.dumps(rec), flush=True)
 
+        # the Listnet flavour: the whole [queries, systems] matrix from ONE launch (ltr_risk_matrix_fwd) + flip + geoRisk
+        def dev_step_ln():
+            ypd.grad = None
+            RL.geoRiskListnetLoss(ypd, ytd, ybd, listnet_transformation=1, add_ideal_ranking_to_mat=2).sum().backward()
+        rec = {"row": "f-1", "what": f"geoRiskListnetLoss fwd+bwd, B={B}, S={S}, {nb} baselines + ideal (one matrix launch + flip + geoRisk)",
+               "gpu_ms": round(gpu_ms(dev_step_ln), 3)}
+        graphed = GraphedLoss(lambda a_, b_, c_: RL.geoRiskListnetLoss(a_, b_, c_, listnet_transformation=1, add_ideal_ranking_to_mat=2),
+                              (ypd.detach(), ytd, ybd))
+        rec["gpu_ms_hipgraph"] = round(gpu_ms(lambda: graphed(ypd.detach(), ytd, ybd)), 3)
+        prof_launches = None
+        try:
+            from torch.profiler import ProfilerActivity, profile
+            with profile(activities=[ProfilerActivity.CUDA]) as pr:
+                dev_step_ln()
+                torch.cuda.synchronize()
+            prof_launches = sum(1 for e in pr.events() if e.device_type is not None and "cuda" in str(e.device_type).lower())
+        except Exception:
+            pass
+        rec["device_kernels_per_step"] = prof_launches
+        print(json.dumps(rec), flush=True)
+
     # ---- f-4: NDCG@10 per query (the reference loops over queries in Python after every epoch) and GeoRisk of 4 systems
     Q, S = 100_000, 128
     y = torch.randint(0, 5, (Q, S), device=dev).float()
