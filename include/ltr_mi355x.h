@@ -123,6 +123,13 @@ int ltr_risk_fwd_bwd(const float *mat, int Q, int n_systems, int col, float alph
 int ltr_trisk_fwd_bwd(const float *model, const float *baseline, int Q, float alpha, float *value, float *dmodel,
                       float *dbaseline, void *stream);
 
+/* The tail of a geoRisk (kind 1) / zRisk (kind 0) loss in one launch (riskLosses.py:47-60, :118-125, :170-180, :237-244): optional
+ * flip mat' = -mat + max(mat), risk of column 0 and (strategies 2 / 3) of the last column, strategy 1: f R0, 2: f (R1 - R0)
+ * [zquirk != 0: f R1 - R0, the reference's precedence in zRiskListnetLoss :176], 3: f (R1 - R0)^2; value [1] and dmat [Q][n] =
+ * d value / d mat (NULL = not wanted; the max passes its gradient to the maximal entries, evenly among ties). */
+int ltr_risk_tail_fwd_bwd(const float *mat, int Q, int n_systems, float alpha, int kind, int strategy, int flip, float factor,
+                          int zquirk, float *value, float *dmat, void *stream);
+
 /* The [queries x systems] effectiveness matrix of the six risk-sensitive losses in ONE launch (losses/riskLosses/riskLosses.py:8-49,
  * :63-117, :128-169, :183-236, :247-276, :294-330), mat [B][1 + n_rest + (ideal != 0)] row-major: column 0 the model, then the
  * baseline rankers, optionally the ideal ranking (the reference vector itself); and jac [B][S] = d mat[b][0] / d x0[b][j] (NULL = not

@@ -141,6 +141,119 @@ inline int status() {
 
 
 // ---------------------------------------------------------------------------------------------------------------------------
+// The TAIL of a geoRisk / zRisk loss in one launch (riskLosses.py:47-60, :118-125, :170-180, :237-244): the "larger = better" flip
+// mat' = -mat + max(mat), the risk of column 0 and (return strategies 2 / 3) of the last column, the strategy's combination, the
+// `negative` factor -- value and d value / d mat (w.r.t. the UNFLIPPED matrix; the whole-matrix max passes its gradient to the
+// maximal entries, evenly among ties, like torch.max) come out together.
+//   strategy 1: f R0      2: f (R1 - R0)   [zquirk: f R1 - R0, the reference's operator precedence in zRiskListnetLoss, :176]
+//   strategy 3: f (R1 - R0)^2
+struct RiskCol { double si, Z, T1, val, dZ, dSi; };
+
+__global__ void __launch_bounds__(kRiskThreads)
+risk_tail_kernel(const float *__restrict__ mat, int Q, int n, float alpha, int geo, int strategy, int flip, float factor, int zquirk,
+                 float *__restrict__ value, float *__restrict__ dmat) {
+    __shared__ double red[kRiskThreads / LTR_WAVE];
+    const int tid = threadIdx.x;
+    double M = 0.0;
+    if (flip) {
+        double mx = -INFINITY;
+        for (int e = tid; e < Q * n; e += kRiskThreads) mx = fmax(mx, (double)mat[e]);
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) mx = fmax(mx, __shfl_xor(mx, o, LTR_WAVE));
+        __syncthreads();
+        if ((tid & (LTR_WAVE - 1)) == 0) red[tid / LTR_WAVE] = mx;
+        __syncthreads();
+        M = red[0];
+        for (int w = 1; w < kRiskThreads / LTR_WAVE; ++w) M = fmax(M, red[w]);
+        M = (double)(float)M;
+    }
+    // the flipped entry in the reference's fp32 arithmetic (-mat + max), then promoted
+    auto at = [&](int q, int j) -> double { return flip ? (double)(-mat[(size_t)q * n + j] + (float)M) : (double)mat[(size_t)q * n + j]; };
+    const int ncol = strategy == 1 ? 1 : 2;
+    const int cols[2] = {0, n - 1};
+    RiskCol rc[2];
+    double s_n = 0.0, s_i0 = 0.0, s_i1 = 0.0;
+    for (int q = tid; q < Q; q += kRiskThreads) {
+        double t = 0.0;
+        for (int j = 0; j < n; ++j) t += at(q, j);
+        s_n += t;
+        s_i0 += at(q, 0);
+        s_i1 += at(q, n - 1);
+    }
+    const double nn = block_sum_f64(s_n, red);
+    rc[0].si = block_sum_f64(s_i0, red);
+    rc[1].si = block_sum_f64(s_i1, red);
+    for (int i = 0; i < ncol; ++i) {
+        const double si = rc[i].si;
+        double z_acc = 0.0, t1_acc = 0.0;
+        for (int q = tid; q < Q; q += kRiskThreads) {
+            double t = 0.0;
+            for (int j = 0; j < n; ++j) t += at(q, j);
+            const double x = at(q, cols[i]);
+            const double e = si * (t / nn);
+            const double d = (x - e) / sqrt(e);
+            const double c = d < 0.0 ? 1.0 + (double)alpha : 1.0;
+            z_acc += c * d;
+            t1_acc += c * (-0.5 * (x + e) / (e * sqrt(e))) * t;
+        }
+        rc[i].Z = block_sum_f64(z_acc, red);
+        rc[i].T1 = block_sum_f64(t1_acc, red) / nn;
+        rc[i].val = rc[i].Z;
+        rc[i].dZ = 1.0;
+        rc[i].dSi = 0.0;
+        if (geo) {
+            const double v = rc[i].Z / (double)Q;
+            const double Phi = 0.5 * erfc(-v * 0.70710678118654752440);
+            const double phi = 0.39894228040143267794 * exp(-0.5 * v * v);
+            const double Mq = si / (double)Q;
+            rc[i].val = sqrt(Mq * Phi);
+            rc[i].dZ = 0.5 / rc[i].val * Mq * phi / (double)Q;
+            rc[i].dSi = 0.5 / rc[i].val * Phi / (double)Q;
+        }
+    }
+    // the reference evaluates each risk in fp32 tensors: round the two values where it does before combining them
+    const double R0 = (double)(float)rc[0].val, R1 = ncol > 1 ? (double)(float)rc[1].val : 0.0, f = (double)factor;
+    double out, c0, c1 = 0.0;
+    if (strategy == 1) { out = f * R0; c0 = f; }
+    else if (strategy == 2) {
+        if (zquirk) { out = f * R1 - R0; c0 = -1.0; c1 = f; }
+        else { out = f * (R1 - R0); c0 = -f; c1 = f; }
+    } else { const double df = R1 - R0; out = f * df * df; c0 = -2.0 * f * df; c1 = 2.0 * f * df; }
+    if (tid == 0) value[0] = (float)out;
+    if (!dmat) return;
+    const double coef[2] = {c0, c1};
+    double g_acc = 0.0;
+    for (int q = tid; q < Q; q += kRiskThreads) {
+        double t = 0.0;
+        for (int j = 0; j < n; ++j) t += at(q, j);
+        double common = 0.0, own[2] = {0.0, 0.0};
+        for (int i = 0; i < ncol; ++i) {
+            const double si = rc[i].si, x = at(q, cols[i]);
+            const double e = si * (t / nn), rs = 1.0 / sqrt(e), d = (x - e) * rs;
+            const double c = d < 0.0 ? 1.0 + (double)alpha : 1.0;
+            const double A = c * (-0.5 * (x + e) * rs / e);
+            common += coef[i] * rc[i].dZ * (A * si / nn - si * rc[i].T1 / nn);
+            own[i] = coef[i] * (rc[i].dZ * (c * rs + rc[i].T1) + rc[i].dSi);
+        }
+        for (int j = 0; j < n; ++j) {
+            double gq = common;
+            if (j == 0) gq += own[0];
+            if (ncol > 1 && j == n - 1) gq += own[1];
+            g_acc += gq;
+            dmat[(size_t)q * n + j] = (float)(flip ? -gq : gq);
+        }
+    }
+    if (flip) {      // d max(mat) / d mat: the sum of all d value / d mat' entries lands on the maximal entries
+        const double G = block_sum_f64(g_acc, red);
+        double ties_a = 0.0;
+        for (int e = tid; e < Q * n; e += kRiskThreads) ties_a += (double)mat[e] == M ? 1.0 : 0.0;
+        const double ties = block_sum_f64(ties_a, red);
+        for (int e = tid; e < Q * n; e += kRiskThreads)
+            if ((double)mat[e] == M) dmat[e] += (float)(G / ties);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
 // The [queries x systems] effectiveness matrix of the risk-sensitive losses, one workgroup per query, one launch for all systems
 // (riskLosses.py:8-49 / :128-169 / :247-276 Listnet type, :63-117 / :183-236 / :294-330 Lambda type) -- and d mat[q][0] / d (the
 // model's input), the only gradient the losses need (column 0 is the model; baselines and the ideal ranking are constants).
@@ -277,6 +390,17 @@ int ltr_trisk_fwd_bwd(const float *model, const float *baseline, int Q, float al
     hipLaunchKernelGGL(trisk_kernel, dim3(1), dim3(kRiskThreads), 0, (hipStream_t)stream, model, baseline, Q, alpha, value,
                        dmodel, dbaseline);
     return status();
+}
+
+int ltr_risk_tail_fwd_bwd(const float *mat, int Q, int n_systems, float alpha, int kind, int strategy, int flip, float factor,
+                          int zquirk, float *value, float *dmat, void *stream) {
+    if (!mat || !value) return LTR_ERR_NULL;
+    if (Q < 1 || n_systems < 1 || (long long)Q * n_systems > (1ll << 30)) return LTR_ERR_SHAPE;
+    if ((kind != 0 && kind != 1) || strategy < 1 || strategy > 3) return LTR_ERR_PARAM;
+    hipLaunchKernelGGL(risk_tail_kernel, dim3(1), dim3(kRiskThreads), 0, (hipStream_t)stream, mat, Q, n_systems, alpha, kind, strategy,
+                       flip ? 1 : 0, factor, zquirk ? 1 : 0, value, dmat);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? LTR_OK : (int)e;
 }
 
 int ltr_risk_matrix_fwd(const float *ref, const float *x0, const float *rest, int B, int S, int n_rest, int mode, int lt, int ideal,

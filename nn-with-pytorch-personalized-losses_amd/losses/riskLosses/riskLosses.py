@@ -84,8 +84,9 @@ def _flip(mat, lt):
 
 
 def _listnet_mat_fused(y_predicted, y_true, y_baselines, lt, add_ideal):
-    """Queries x systems matrix of the Listnet-type losses in one launch (softmaxes, transformation, every system); None when
-    the shapes are not the regular ones."""
+    """Queries x systems matrix of the Listnet-type losses in one launch (softmaxes, transformation, every system), BEFORE the
+    "larger = better" flip of :47-49, and whether that flip applies (the risk tail does it); None when the shapes are not the
+    regular ones."""
     require_device(y_predicted, y_true)
     reg = _regular(y_predicted, y_true, y_baselines)
     if reg is None:
@@ -93,7 +94,7 @@ def _listnet_mat_fused(y_predicted, y_true, y_baselines, lt, add_ideal):
     if lt not in (1, 2, 3):
         _unbound()
     yp, yt, yb = reg
-    return _flip(_risk.risk_matrix(yt, yp, yb, 0, lt, add_ideal == 2), lt)
+    return _risk.risk_matrix(yt, yp, yb, 0, lt, add_ideal == 2), lt in (1, 3)       # (matrix BEFORE the flip, whether it is flipped)
 
 
 def _listnet_mat(p_true, p_pred, p_base, lt, add_ideal):
@@ -132,7 +133,7 @@ def _lambda_mat(p_true, p_pred, p_base, lt, add_ideal, scheme, ideal_is_ones):
         mat = _risk.risk_matrix(tt, cp, None if cb is None else cb.contiguous(), 1, lt, add_ideal == 2 and not ones_col)
         if ones_col:
             mat = torch.cat([mat, torch.ones((B, 1), dtype=mat.dtype, device=mat.device)], 1)        # :106
-        return -mat + torch.max(mat) if lt == 1 else mat
+        return mat, lt == 1                      # (matrix BEFORE the flip, whether it is flipped: the risk tail does it)
     parts = [cp.unsqueeze(0)] + ([cb] if cb is not None else [])
     if add_ideal == 2 and not ones_col:
         parts.append(tt.unsqueeze(0))
@@ -142,7 +143,28 @@ def _lambda_mat(p_true, p_pred, p_base, lt, add_ideal, scheme, ideal_is_ones):
     mat = mat.t()
     if lt == 1:
         mat = -mat + torch.max(mat)
-    return mat
+    return mat, False
+
+
+def _tail(kind, mat, flip, alpha, return_strategy, negative, zquirk=False):
+    """Flip, risk of the model column (and of the last one), return strategy, `negative`: one launch for a regular fp32 matrix."""
+    if return_strategy not in (1, 2, 3):
+        return None
+    if mat.dim() == 2 and mat.dtype == torch.float32 and mat.shape[0] > 0 and not isinstance(negative, torch.Tensor):
+        return _risk.risk_tail(mat, alpha, kind, return_strategy, flip, float(negative), zquirk)
+    if flip:
+        mat = -mat + torch.max(mat)
+    risk = geoRisk if kind == _risk.RISK_GEO else zRisk
+    factor = _factor(negative, mat)
+    if zquirk:
+        # the reference's operator precedence (:176-178): `factor` multiplies only the first term of strategy 2 and the squared
+        # difference of strategy 3
+        if return_strategy == 1:
+            return factor * risk(mat, alpha, requires_grad=True)
+        if return_strategy == 2:
+            return factor * risk(mat, alpha, requires_grad=True, i=-1) - risk(mat, alpha, requires_grad=True)
+        return factor * (risk(mat, alpha, requires_grad=True, i=-1) - risk(mat, alpha, requires_grad=True)) ** 2
+    return _by_strategy(risk, mat, alpha, return_strategy, factor)
 
 
 def _factor(negative, like):
@@ -160,45 +182,40 @@ def _by_strategy(risk, mat, alpha, return_strategy, factor):
     return None
 
 
+def _listnet_matrix(y_predicted, y_true, y_baselines, lt, add_ideal):
+    """(matrix, flip still to be applied?) of the Listnet-type losses: one launch for the regular shapes, else the tensor algebra."""
+    fm = _listnet_mat_fused(y_predicted, y_true, y_baselines, lt, add_ideal)
+    if fm is not None:
+        return fm
+    p_true, p_pred, p_base = _probs(y_predicted, y_true, y_baselines)
+    return _listnet_mat(p_true, p_pred, p_base, lt, add_ideal), False
+
+
 def geoRiskListnetLoss(y_predicted, y_true, y_baselines=None, alpha=5, listnet_transformation=1, return_strategy=1,
                        negative=1, add_ideal_ranking_to_mat=1):
-    mat = _listnet_mat_fused(y_predicted, y_true, y_baselines, listnet_transformation, add_ideal_ranking_to_mat)
-    if mat is None:
-        p_true, p_pred, p_base = _probs(y_predicted, y_true, y_baselines)
-        mat = _listnet_mat(p_true, p_pred, p_base, listnet_transformation, add_ideal_ranking_to_mat)
-    return _by_strategy(geoRisk, mat, alpha, return_strategy, _factor(negative, mat))
+    mat, flip = _listnet_matrix(y_predicted, y_true, y_baselines, listnet_transformation, add_ideal_ranking_to_mat)
+    return _tail(_risk.RISK_GEO, mat, flip, alpha, return_strategy, negative)
 
 
 def geoRiskLambdaLoss(y_predicted, y_true, y_baselines=None, alpha=5, listnet_transformation=1, return_strategy=1,
                       negative=1, add_ideal_ranking_to_mat=1, weighing_scheme="ndcgLoss2PP_scheme"):
     p_true, p_pred, p_base = _probs(y_predicted, y_true, y_baselines)
-    mat = _lambda_mat(p_true, p_pred, p_base, listnet_transformation, add_ideal_ranking_to_mat, weighing_scheme, True)
-    return _by_strategy(geoRisk, mat, alpha, return_strategy, _factor(negative, mat))
+    mat, flip = _lambda_mat(p_true, p_pred, p_base, listnet_transformation, add_ideal_ranking_to_mat, weighing_scheme, True)
+    return _tail(_risk.RISK_GEO, mat, flip, alpha, return_strategy, negative)
 
 
 def zRiskListnetLoss(y_predicted, y_true, y_baselines=None, alpha=5, listnet_transformation=1, return_strategy=1,
                      negative=1, add_ideal_ranking_to_mat=1):
-    mat = _listnet_mat_fused(y_predicted, y_true, y_baselines, listnet_transformation, add_ideal_ranking_to_mat)
-    if mat is None:
-        p_true, p_pred, p_base = _probs(y_predicted, y_true, y_baselines)
-        mat = _listnet_mat(p_true, p_pred, p_base, listnet_transformation, add_ideal_ranking_to_mat)
-    factor = _factor(negative, mat)
-    # the reference's operator precedence (:176-178): `factor` multiplies only the first term of strategy 2 and
-    # the squared difference of strategy 3
-    if return_strategy == 1:
-        return factor * zRisk(mat, alpha, requires_grad=True)
-    elif return_strategy == 2:
-        return factor * zRisk(mat, alpha, requires_grad=True, i=-1) - zRisk(mat, alpha, requires_grad=True)
-    elif return_strategy == 3:
-        return factor * (zRisk(mat, alpha, requires_grad=True, i=-1) - zRisk(mat, alpha, requires_grad=True)) ** 2
-    return None
+    mat, flip = _listnet_matrix(y_predicted, y_true, y_baselines, listnet_transformation, add_ideal_ranking_to_mat)
+    # (zquirk: the reference's operator precedence, :176-178 -- `factor` multiplies only the first term of strategy 2)
+    return _tail(_risk.RISK_Z, mat, flip, alpha, return_strategy, negative, zquirk=True)
 
 
 def zRiskLambdaLoss(y_predicted, y_true, y_baselines=None, alpha=5, listnet_transformation=1, return_strategy=1,
                     negative=1, add_ideal_ranking_to_mat=1, weighing_scheme="ndcgLoss2PP_scheme"):
     p_true, p_pred, p_base = _probs(y_predicted, y_true, y_baselines)
-    mat = _lambda_mat(p_true, p_pred, p_base, listnet_transformation, add_ideal_ranking_to_mat, weighing_scheme, False)
-    return _by_strategy(zRisk, mat, alpha, return_strategy, _factor(negative, mat))
+    mat, flip = _lambda_mat(p_true, p_pred, p_base, listnet_transformation, add_ideal_ranking_to_mat, weighing_scheme, False)
+    return _tail(_risk.RISK_Z, mat, flip, alpha, return_strategy, negative)
 
 
 def _trisk_tail(mat, lt, alpha, negative):

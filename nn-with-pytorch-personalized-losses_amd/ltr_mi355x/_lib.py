@@ -38,6 +38,7 @@ _PROTOTYPES = {
                                       P, P, P]),
     "ltr_risk_fwd_bwd": (c_int, [P, c_int, c_int, c_int, c_float, c_int, P, P, P]),
     "ltr_trisk_fwd_bwd": (c_int, [P, P, c_int, c_float, P, P, P, P]),
+    "ltr_risk_tail_fwd_bwd": (c_int, [P, c_int, c_int, c_float, c_int, c_int, c_int, c_float, c_int, P, P, P]),
     "ltr_risk_matrix_fwd": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P, P, P]),
     "ltr_ndcg_at_k": (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, c_int, P, P, P]),
     "ltr_svmlight_scan": (c_int, [c_char_p, P, P, P, c_int]),

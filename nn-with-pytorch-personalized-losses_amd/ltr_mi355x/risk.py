@@ -121,6 +121,33 @@ class RiskMatrix(torch.autograd.Function):
         return None, (jac * g[:, 0:1].to(torch.float32)).to(ctx.in_dtype), None, None, None, None
 
 
+class RiskTail(torch.autograd.Function):
+    """Flip + risk of column 0 (and of the last column) + return strategy + `negative` factor of a geoRisk / zRisk loss in one
+    launch (riskLosses.py:47-60, :118-125) -> ltr_risk_tail_fwd_bwd; value [1] and d value / d mat from the same launch."""
+
+    @staticmethod
+    def forward(ctx, mat, alpha, kind, strategy, flip, factor, zquirk):
+        Q, n = mat.shape
+        with torch.cuda.device(mat.device):
+            m = _f32(mat)
+            out = torch.empty(1, dtype=torch.float32, device=mat.device)
+            dmat = torch.empty_like(m) if ctx.needs_input_grad[0] else None
+            check(lib().ltr_risk_tail_fwd_bwd(_ptr(m), Q, n, float(alpha), int(kind), int(strategy), int(bool(flip)), float(factor),
+                                              int(bool(zquirk)), _ptr(out), _ptr(dmat), _stream()), "ltr_risk_tail_fwd_bwd")
+        ctx.save_for_backward(dmat)
+        return out
+
+    @staticmethod
+    def backward(ctx, go):
+        (dmat,) = ctx.saved_tensors
+        return (dmat * go.to(torch.float32),) + (None,) * 6
+
+
+def risk_tail(mat, alpha, kind, strategy, flip, factor, zquirk=False):
+    require_device(mat)
+    return RiskTail.apply(mat, alpha, kind, strategy, flip, factor, zquirk)
+
+
 def risk_matrix(ref, x0, rest, mode, lt, ideal):
     require_device(ref, x0)
     return RiskMatrix.apply(ref, x0, rest, mode, lt, ideal)

@@ -139,8 +139,9 @@ def test_fused_risk_matrix_matches_the_tensor_algebra_path(B, S, nb, lt, ideal, 
     yp, yt = torch.randn(B, S, generator=gen), torch.randint(0, 5, (B, S), generator=gen).float()
     yb = torch.randn(B, S, nb, generator=gen) if nb else None
     x = yp.to(dev).requires_grad_(True)
-    mat = RL._listnet_mat_fused(x, yt.to(dev), None if yb is None else yb.to(dev), lt, ideal)
-    assert mat is not None and mat.shape == (B, 1 + nb + (ideal == 2))
+    mat, flip = RL._listnet_mat_fused(x, yt.to(dev), None if yb is None else yb.to(dev), lt, ideal)
+    assert mat.shape == (B, 1 + nb + (ideal == 2)) and flip == (lt in (1, 3))
+    mat = RL._flip(mat, lt)
     w = torch.randn(mat.shape, generator=gen).to(dev)
     (mat * w).sum().backward()
     x64 = yp.double().to(dev).requires_grad_(True)
@@ -160,6 +161,37 @@ def test_fused_risk_matrix_matches_the_tensor_algebra_path(B, S, nb, lt, ideal, 
         (r1 * w.double()).sum().backward()
         assert relerr(m1.detach().cpu().numpy(), r1.detach().cpu().numpy()) < 2e-6
         assert relerr(c.grad.cpu().numpy(), c64.grad.cpu().numpy()) < 1e-5
+
+
+@pytest.mark.parametrize("Q,n", [(2, 2), (100, 5), (37, 1), (2000, 4)])
+@pytest.mark.parametrize("kind", ["geo", "z"])
+@pytest.mark.parametrize("strategy", [1, 2, 3])
+@pytest.mark.parametrize("flip", [False, True])
+def test_fused_risk_tail_matches_the_tensor_algebra_path(Q, n, kind, strategy, flip, dev):
+    """ltr_risk_tail_fwd_bwd (flip + risk of column 0 and of the last column + return strategy + `negative` in one launch) against
+    the same tail through torch ops and the per-column risk kernels (an fp64 matrix takes that path), value and gradient, incl. the
+    reference's precedence quirk of zRiskListnetLoss and the max's gradient under the flip."""
+    from losses.riskLosses import riskLosses as RL
+    from ltr_mi355x import risk as R
+    gen = torch.Generator().manual_seed(Q * 10 + n + strategy)
+    base = torch.rand(Q, n, generator=gen) * 0.8 + 0.1
+    k = R.RISK_GEO if kind == "geo" else R.RISK_Z
+    for negative, zq in ((1, False), (-1, False), (-1, kind == "z")):
+        m32 = base.to(dev).requires_grad_(True)
+        out = RL._tail(k, m32, flip, 5, strategy, negative, zquirk=zq)
+        out.sum().backward()
+        m64 = base.double().to(dev).requires_grad_(True)
+        ref = RL._tail(k, m64, flip, 5, strategy, negative, zquirk=zq)
+        ref.sum().backward()
+        assert out.shape == (1,)
+        if bool(torch.isnan(ref).any()):                         # one system, flipped: the maximal entry becomes e = 0 -> 0 / 0, both ways
+            assert bool(torch.isnan(out).all())
+            continue
+        # strategies 2 / 3 subtract two risks that both paths round to fp32 first: compare on the scale of the risks themselves
+        scale = max(float(ref.abs().max()), 1e-2)                 # (a single system has zRisk = 0 identically)
+        assert float((out.double() - ref.double()).abs().max()) / scale < 5e-5
+        gs = max(float(m64.grad.abs().max()), 1e-6)
+        assert float((m32.grad.double() - m64.grad).abs().max()) / gs < 2e-4, (kind, strategy, flip, negative)
 
 
 def test_risk_loss_errors_and_larger_batch(dev):
