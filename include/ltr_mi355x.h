@@ -138,6 +138,7 @@ int ltr_risk_tail_fwd_bwd(const float *mat, int Q, int n_systems, float alpha, i
  *     (:10-12), then lt 1: sum (t p - t^2)^2, 2: cosine(t, p), 3: (sum t p - sum t^2)^2.
  *   mode 1 (Lambda type): ref, x0, rest [n_rest][B][S] are lambdaMask column sums (ltr_lambda_colsum_fwd), taken as they are;
  *     lt 1: sum (x - t)^2, 2: cosine(t, x), 3: (sum x - sum t)^2.
+ *   mode 2 (tRiskListnetLoss, :247-276): as mode 0 except lt 2 = cosine(t^2, t p), the cosine of the products.
  * The caller applies the `-mat + max(mat)` flip of lt 1 / 3 (:47-49; a whole-matrix maximum).  S <= 2048. */
 int ltr_risk_matrix_fwd(const float *ref, const float *x0, const float *rest, int B, int S, int n_rest, int mode, int lt, int ideal,
                         float *mat, float *jac, void *stream);

@@ -261,6 +261,7 @@ risk_tail_kernel(const float *__restrict__ mat, int Q, int n, float alpha, int g
 //     the slate first (:10-12);  lt 1: sum_j (t p - t^2)^2   lt 2: cos(t, p)   lt 3: (sum t p - sum t^2)^2        (:16-46)
 //   mode 1 (Lambda type): ref / x0 / rest [nr][B][S] are the lambdaMask column sums, used as they are;
 //     lt 1: sum_j (x - t)^2   lt 2: cos(t, x)   lt 3: (sum x - sum t)^2                                          (:71-104)
+//   mode 2 (the tRisk Listnet loss, :247-276): as mode 0, but transformation 2 is the cosine of the PRODUCTS, cos(t^2, t p).
 //   ideal != 0 appends the column of the reference vector itself.
 // fp32 elementwise arithmetic, fp64 sums, fixed-order reductions.  The cosine follows ATen: w12 / sqrt(max(w1 w2, eps^2)), eps 1e-8.
 constexpr int kMatThreads = 256;
@@ -310,7 +311,7 @@ risk_matrix_kernel(const float *__restrict__ ref, const float *__restrict__ x0, 
     const int b = blockIdx.x, tid = threadIdx.x, nsys = 1 + nr + (ideal ? 1 : 0);
     for (int j = tid; j < S; j += kMatThreads) t[j] = ref[(size_t)b * S + j];
     __syncthreads();
-    if (mode == 0) mat_softmax(t, S, red);
+    if (mode != 1) mat_softmax(t, S, red);
     double nt_a = 0.0, st_a = 0.0;
     for (int j = tid; j < S; j += kMatThreads) {
         nt_a += (double)t[j] * t[j];
@@ -324,37 +325,49 @@ risk_matrix_kernel(const float *__restrict__ ref, const float *__restrict__ x0, 
             float v;
             if (is_ideal) v = t[j];
             else if (sys == 0) v = x0[(size_t)b * S + j];
-            else v = mode == 0 ? rest[((size_t)b * S + j) * nr + (sys - 1)] : rest[((size_t)(sys - 1) * B + b) * S + j];
+            else v = mode != 1 ? rest[((size_t)b * S + j) * nr + (sys - 1)] : rest[((size_t)(sys - 1) * B + b) * S + j];
             x[j] = v;
         }
         __syncthreads();
-        if (mode == 0 && !is_ideal) mat_softmax(x, S, red);
-        double a_a = 0.0, nx_a = 0.0, c_a = 0.0, sx_a = 0.0;
+        if (mode != 1 && !is_ideal) mat_softmax(x, S, red);
+        double a_a = 0.0, nx_a = 0.0, c_a = 0.0, sx_a = 0.0, ac_a = 0.0, nu_a = 0.0, nv_a = 0.0;
         for (int j = tid; j < S; j += kMatThreads) {
             const float tj = t[j], xj = x[j];
             a_a += (double)tj * xj;
             nx_a += (double)xj * xj;
             sx_a += (double)xj;
-            const float df = mode == 0 ? tj * xj - tj * tj : xj - tj;
+            const float df = mode == 1 ? xj - tj : tj * xj - tj * tj;
             c_a += (double)df * df;
+            if (mode == 2) {                       // the tRisk pair's cosine is taken between the PRODUCTS t^2 and t x (:256-258)
+                const float u = tj * tj, v = tj * xj;
+                ac_a += (double)u * v;
+                nu_a += (double)u * u;
+                nv_a += (double)v * v;
+            }
         }
         const double a = mat_block_sum(a_a, red), nx = mat_block_sum(nx_a, red), c = mat_block_sum(c_a, red), sx = mat_block_sum(sx_a, red);
-        const double den2 = nt * nx > 1e-16 ? nt * nx : 1e-16, den = sqrt(den2);
+        // cosine operands: (u, v) = (t, x) [modes 0, 1] or (t^2, t x) [mode 2]
+        const double ca = mode == 2 ? mat_block_sum(ac_a, red) : a, cnu = mode == 2 ? mat_block_sum(nu_a, red) : nt,
+                     cnv = mode == 2 ? mat_block_sum(nv_a, red) : nx;
+        const double den2 = cnu * cnv > 1e-16 ? cnu * cnv : 1e-16, den = sqrt(den2);
         double m;
         if (lt == 1) m = c;
-        else if (lt == 2) m = a / den;
-        else m = mode == 0 ? (a - nt) * (a - nt) : (sx - st) * (sx - st);
+        else if (lt == 2) m = ca / den;
+        else m = mode == 1 ? (sx - st) * (sx - st) : (a - nt) * (a - nt);
         if (tid == 0) mat[(size_t)b * nsys + sys] = (float)m;
         if (sys == 0 && jac) {
             // g_j = d m / d x_j; mode 0: x = softmax(s): d m / d s_j = x_j (g_j - sum_k x_k g_k)
-            const bool clamped = !(nt * nx > 1e-16);
+            const bool clamped = !(cnu * cnv > 1e-16);
             auto grad = [&](int j) -> double {
                 const double tj = t[j], xj = x[j];
-                if (lt == 1) return mode == 0 ? 2.0 * tj * (tj * xj - tj * tj) : 2.0 * (xj - tj);
-                if (lt == 2) return clamped ? tj / den : tj / den - m * xj / nx;
-                return mode == 0 ? 2.0 * (a - nt) * tj : 2.0 * (sx - st);
+                if (lt == 1) return mode == 1 ? 2.0 * (xj - tj) : 2.0 * tj * (tj * xj - tj * tj);
+                if (lt == 2) {
+                    const double u = mode == 2 ? tj * tj : tj, v = mode == 2 ? tj * xj : xj, w = mode == 2 ? tj : 1.0;
+                    return w * (clamped ? u / den : u / den - m * v / cnv);
+                }
+                return mode == 1 ? 2.0 * (sx - st) : 2.0 * (a - nt) * tj;
             };
-            if (mode == 0) {
+            if (mode != 1) {
                 double dot_a = 0.0;
                 for (int j = tid; j < S; j += kMatThreads) dot_a += (double)x[j] * grad(j);
                 const double dot = mat_block_sum(dot_a, red);
@@ -407,7 +420,7 @@ int ltr_risk_matrix_fwd(const float *ref, const float *x0, const float *rest, in
                         float *mat, float *jac, void *stream) {
     if (!ref || !x0 || !mat || (n_rest > 0 && !rest)) return LTR_ERR_NULL;
     if (B < 0 || S < 1 || S > kMatMaxS || n_rest < 0 || n_rest > 64) return LTR_ERR_SHAPE;
-    if ((mode != 0 && mode != 1) || lt < 1 || lt > 3) return LTR_ERR_PARAM;
+    if (mode < 0 || mode > 2 || lt < 1 || lt > 3) return LTR_ERR_PARAM;
     if (B == 0) return LTR_OK;
     hipLaunchKernelGGL(risk_matrix_kernel, dim3(B), dim3(kMatThreads), (size_t)2 * S * sizeof(float), (hipStream_t)stream, ref, x0, rest, B,
                        S, n_rest, mode, lt, ideal ? 1 : 0, mat, jac);

@@ -8,8 +8,9 @@ function.  On the MI355X: the pair-matrix column sums of the Lambda variants com
 (no [B,S,S] tensor is ever written), the risk reductions from `ltr_risk_fwd_bwd` / `ltr_trisk_fwd_bwd`
 (forward + analytic gradient per launch), and -- for the regular shapes of the geoRisk / zRisk losses -- the whole
 [queries, systems] matrix from ONE launch (`ltr_risk_matrix_fwd`: softmaxes, transformation, every system, and the
-gradient of the model's column).  Irregular shapes (a squeezed single baseline, B = 1, ...) and the tRisk pair walk the
-tensor-algebra path, which reproduces the reference's squeeze quirks literally.  Device tensors only.
+gradient of the model's column); the tRisk pair takes its [queries, 2] matrix from the same kernel.  Irregular shapes (a
+squeezed single baseline, B = 1, fp64 inputs, ...) walk the tensor-algebra path, which reproduces the reference's squeeze
+quirks literally.  Device tensors only.
 """
 import torch
 import torch.nn.functional as F
@@ -226,7 +227,31 @@ def _trisk_tail(mat, lt, alpha, negative):
     return _factor(negative, mat) * _risk.TRisk.apply(mat[0], mat[1], alpha)
 
 
+def _regular_pair(y_predicted, y_true, y_baseline):
+    """tRisk: ONE baseline [B, S] (or [B, S, 1]) next to regular scores / labels."""
+    if y_baseline is None or not isinstance(y_baseline, torch.Tensor):
+        return None
+    yb = y_baseline[:, :, 0] if y_baseline.dim() == 3 and y_baseline.shape[2] == 1 else y_baseline
+    reg = _regular(y_predicted, y_true, None)
+    if reg is None or yb.dim() != 2 or tuple(yb.shape) != tuple(reg[0].shape) or yb.dtype != torch.float32:
+        return None
+    return reg[0], reg[1], yb
+
+
+def _trisk_pair_tail(mat, lt, alpha, negative):
+    """[B, 2] (model, baseline) -> flip (transformation 1 only, :269-271) -> tRisk."""
+    if lt == 1:
+        mat = -mat + torch.max(mat)
+    return _factor(negative, mat) * _risk.TRisk.apply(mat[:, 0], mat[:, 1], alpha)
+
+
 def tRiskListnetLoss(y_predicted, y_true, y_baselines, alpha=5, listnet_transformation=1, negative=1):
+    reg = _regular_pair(y_predicted, y_true, y_baselines)
+    if reg is not None and listnet_transformation in (1, 2, 3):
+        require_device(y_predicted, y_true)
+        yp, yt, yb = reg                          # one launch: softmaxes, transformation, model and baseline columns (+ gradient)
+        return _trisk_pair_tail(_risk.risk_matrix(yt, yp, yb.unsqueeze(2).contiguous(), 2, listnet_transformation, False),
+                                listnet_transformation, alpha, negative)
     p_true, p_pred, p_base = _probs(y_predicted, y_true, y_baselines)
     q_true, q_pred, q_base = p_true * p_true, p_true * p_pred, p_true * p_base
     if listnet_transformation == 1:
@@ -246,6 +271,10 @@ def tRiskLambdaLoss(y_predicted, y_true, y_baselines, alpha=5, listnet_transform
     p_true, p_pred, p_base = _probs(y_predicted, y_true, y_baselines)
     cs = lambda p: _risk.lambda_colsum(p, p_true, weighing_scheme)                          # noqa: E731
     q_true, q_pred, q_base = cs(p_true), cs(p_pred), cs(p_base)
+    if (listnet_transformation in (1, 2, 3) and q_pred.dim() == 2 and q_pred.dtype == torch.float32 and q_base.shape == q_pred.shape
+            and 1 < q_pred.shape[1] <= _FUSED_MAX_SLATE):
+        mat = _risk.risk_matrix(q_true, q_pred, q_base.unsqueeze(0).contiguous(), 1, listnet_transformation, False)
+        return _trisk_pair_tail(mat, listnet_transformation, alpha, negative)
     if listnet_transformation == 1:
         mat = [(q_pred - q_true) ** 2, (q_base - q_true) ** 2]
     elif listnet_transformation == 2:

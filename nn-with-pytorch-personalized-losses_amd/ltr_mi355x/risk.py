@@ -103,7 +103,7 @@ class RiskMatrix(torch.autograd.Function):
     @staticmethod
     def forward(ctx, ref, x0, rest, mode, lt, ideal):
         B, S = x0.shape
-        nr = 0 if rest is None else (rest.shape[2] if mode == 0 else rest.shape[0])
+        nr = 0 if rest is None else (rest.shape[0] if mode == 1 else rest.shape[2])
         with torch.cuda.device(x0.device):
             r, x = _f32(ref), _f32(x0)
             rs = None if rest is None else _f32(rest)

@@ -194,6 +194,28 @@ def test_fused_risk_tail_matches_the_tensor_algebra_path(Q, n, kind, strategy, f
         assert float((m32.grad.double() - m64.grad).abs().max()) / gs < 2e-4, (kind, strategy, flip, negative)
 
 
+@pytest.mark.parametrize("B,S", [(2, 8), (7, 33), (100, 128), (5, 600)])
+@pytest.mark.parametrize("lt", [1, 2, 3])
+@pytest.mark.parametrize("fn", ["tRiskListnetLoss", "tRiskLambdaLoss"])
+def test_trisk_pair_through_the_fused_matrix(B, S, lt, fn, dev):
+    """The tRisk pair takes its [queries, 2] matrix from ltr_risk_matrix_fwd (mode 2: the Listnet flavour's cosine is taken between
+    the PRODUCTS t^2 and t p; mode 1 for the column sums of the Lambda flavour): fp32 inputs (fused) against fp64 inputs (the
+    tensor-algebra path), value and gradient."""
+    from losses.riskLosses import riskLosses as RL
+    gen = torch.Generator().manual_seed(B * 100 + S + lt)
+    yp, yt, yb = torch.randn(B, S, generator=gen), torch.randint(0, 5, (B, S), generator=gen).float(), torch.randn(B, S, generator=gen)
+    x = yp.to(dev).requires_grad_(True)
+    out = getattr(RL, fn)(x, yt.to(dev), yb.to(dev), alpha=5, listnet_transformation=lt)
+    out.sum().backward()
+    x64 = yp.double().to(dev).requires_grad_(True)
+    ref = getattr(RL, fn)(x64, yt.double().to(dev), yb.double().to(dev), alpha=5, listnet_transformation=lt)
+    ref.sum().backward()
+    # mean / std of per-query deltas, a ratio of small differences, from fp32 column sums against fp64 ones: 1e-3 (the goldens
+    # pin the same functions at max(1e-5, 4 x the reference's own fp32 noise) in test_risk_losses_golden)
+    assert relerr(out.detach().cpu().numpy(), ref.detach().cpu().numpy()) < 1e-3
+    assert relerr(x.grad.cpu().numpy(), x64.grad.cpu().numpy()) < 1e-3
+
+
 def test_risk_loss_errors_and_larger_batch(dev):
     from losses.riskLosses import riskLosses as RL
     gen = torch.Generator().manual_seed(5)
