@@ -34,6 +34,12 @@
 #define FCW_STAMP(k)
 #endif
 
+#ifndef FCW_KEEP_R
+#define FCW_KEEP_R 1               // pair reciprocals of the approxNDCG sweeps stay in registers between the two sweeps (64 VGPRs)
+#endif
+#ifndef FCW_W1_RELOAD
+#define FCW_W1_RELOAD 1            // exact fp32: the W1 fragments are re-read from L2 per tile (9 KB per wave) instead of pinning 36 VGPRs through
+#endif                             // the loss and dW1 phases
 constexpr int kFcwWaves = 4;
 constexpr int kFcwThreads = kFcwWaves * 64;
 
@@ -49,9 +55,12 @@ constexpr size_t fcw_lds() {
 #endif
 }
 
-template <class N, int LOSS>
+// ST: the slate length when it is a compile-time constant (approxNDCG: one kernel per slate length, so that each carries ONE
+// copy of the loss with fixed geometry -- three copies in one kernel cost it 90 B/lane of scratch); 0 = a.S at run time.
+template <class N, int LOSS, int ST>
 __global__ void __launch_bounds__(kFcwThreads, 2) fcw_fused_kernel(const PipeArgs a) {
     static_assert(N::TWO && N::H1 == 16 * kFcwWaves, "one hidden tile per wave");
+    static_assert(ST == 0 || ST == 32 || ST == 64 || ST == 128, "slate length");
     constexpr int XT = N::XT;
     extern __shared__ __attribute__((aligned(16))) float smem_f[];
 #if LTR_F16X2
@@ -85,6 +94,9 @@ __global__ void __launch_bounds__(kFcwThreads, 2) fcw_fused_kernel(const PipeArg
     const float b3 = a.packed[N::W3_OFF + N::NT2 * 16];
 #if LTR_F16X2
     h16x8 wh[KP], wl[KP];
+#if FCW_W1_RELOAD
+    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.packed), 0, N::PACKED * 4, 0x00020000);
+#else
     {
         const uint4 *src = reinterpret_cast<const uint4 *>(a.packed + N::W1B_OFF) + (size_t)w * KP * 2 * 64 + lane;
 #pragma unroll
@@ -93,6 +105,7 @@ __global__ void __launch_bounds__(kFcwThreads, 2) fcw_fused_kernel(const PipeArg
             wl[P] = __builtin_bit_cast(h16x8, src[(2 * P + 1) * 64]);
         }
     }
+#endif
     const float inv_w1 = a.packed[N::W3_OFF + N::NT2 * 16 + 4];
     float w3max = 0.f;
     for (int j = lane; j < N::H2; j += 64) w3max = fmaxf(w3max, fabsf(a.packed[N::W3_OFF + j]));
@@ -106,11 +119,15 @@ __global__ void __launch_bounds__(kFcwThreads, 2) fcw_fused_kernel(const PipeArg
     int exx = 1, exd = -100, E = -400;
 #else
     f32x4 wf[XT];                                    // lane (n, q): W1aug[16 w + n][16 S + 4 q .. + 3]
+#if FCW_W1_RELOAD
+    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.packed), 0, N::PACKED * 4, 0x00020000);
+#else
     {
         const f32x4 *src = reinterpret_cast<const f32x4 *>(a.packed + N::W1F_OFF) + (size_t)w * XT * 64 + lane;
 #pragma unroll
         for (int S = 0; S < XT; ++S) wf[S] = src[S * 64];
     }
+#endif
     for (int e = tid; e < kTileDocs * 4; e += kFcwThreads) Xs[(e >> 2) * LDX + N::F + (e & 3)] = (e & 3) ? 0.f : 1.f;
 #endif
     for (int j = tid; j < kFcwThreads + 4 * 32; j += kFcwThreads) scratch[j] = 0.f;
@@ -146,6 +163,25 @@ __global__ void __launch_bounds__(kFcwThreads, 2) fcw_fused_kernel(const PipeArg
             for (int r = 0; r < 4; ++r) xm = fmaxf(xm, fabsf(xn[m][r]));
         xm = wave_allmax(xm);
 #endif
+#if FCW_W1_RELOAD
+        {   // this wave's W1 fragments, L2 -> registers, behind the X loads (consumed in fc1, two barriers from here); the byte offset
+            // is laundered per tile so that the loads are not hoisted out of the persistent loop and pinned for the whole kernel
+#if LTR_F16X2
+            int wo = N::W1B_OFF * 4 + w * KP * 2 * 1024;
+            asm volatile("" : "+s"(wo));
+#pragma unroll
+            for (int P = 0; P < KP; ++P) {
+                wh[P] = __builtin_bit_cast(h16x8, load_frag(wrs, lane * 16, wo + (2 * P) * 1024));
+                wl[P] = __builtin_bit_cast(h16x8, load_frag(wrs, lane * 16, wo + (2 * P + 1) * 1024));
+            }
+#else
+            int wo = (N::W1F_OFF + w * XT * 256) * 4;
+            asm volatile("" : "+s"(wo));
+#pragma unroll
+            for (int S = 0; S < XT; ++S) wf[S] = load_frag(wrs, lane * 16, wo + S * 1024);
+#endif
+        }
+#endif
         FCW_STAMP(1)
         __syncthreads();                              // A: every wave is done with the previous tile's images, scores, gradients
 #if LTR_F16X2
@@ -153,9 +189,9 @@ __global__ void __launch_bounds__(kFcwThreads, 2) fcw_fused_kernel(const PipeArg
 #endif
         if (tid < kTileDocs) {
             const long long doc = doc_base + tid;
-            const float y = doc < (long long)a.B * a.S ? a.labels[doc] : a.pad;
+            const float y = doc < a.n_docs ? a.labels[doc] : a.pad;
             if (LOSS != 1) stage_label(y, a.pad, yl[tid], gn[tid]);
-            else yl[tid] = doc < (long long)a.B * a.S ? y : 0.f;
+            else yl[tid] = doc < a.n_docs ? y : 0.f;
         }
 #if LTR_F16X2
         __syncthreads();                              // B: the four row-block maxima are out
@@ -298,32 +334,36 @@ __global__ void __launch_bounds__(kFcwThreads, 2) fcw_fused_kernel(const PipeArg
         }
         FCW_STAMP(5)
         __syncthreads();                              // D: the four partials of every document are out
-        if (tid < kTileDocs) sc[tid] = ((part[tid] + part[kTileDocs + tid]) + (part[2 * kTileDocs + tid] + part[3 * kTileDocs + tid])) + b3;
-        __syncthreads();
+        if (LOSS != 0) {                              // (approxNDCG sums the partials inside its wave-private prologue: no second barrier)
+            if (tid < kTileDocs) sc[tid] = ((part[tid] + part[kTileDocs + tid]) + (part[2 * kTileDocs + tid] + part[3 * kTileDocs + tid])) + b3;
+            __syncthreads();
+        }
         FCW_STAMP(6)
         // ---- listwise loss on the LDS-resident scores -> dsc (2 threads per document row)
         {
-            const int group = 2 * a.S;
+            const int S_ = ST ? ST : a.S;
+            const int group = 2 * S_;
             const int gid = tid / group;
-            const SlateGroup g = make_group(a.S, group, scratch + gid * (group + 32), tid);
-            const int so = gid * a.S;
-            const long long slate = (long long)st * (kTileDocs / a.S) + gid;
+            const SlateGroup g = make_group(S_, group, scratch + gid * (group + 32), tid);
+            const int so = gid * S_;
+            const long long slate = (long long)st * (kTileDocs / S_) + gid;
             float loss;
-            if (LOSS == 0) {
-                auto st_ds = [&](int i, float v) { dsc[so + i] = v; };
-                ApproxScratch xs;
-                xs.um = xt + so;
+            if constexpr (LOSS == 0) {
+                // one slate per 2 S threads; every wave of a slate sums the score partials of ALL its documents itself
                 auto stamp_fn = [&](int k) { FCW_STAMP(k) };
-                if (a.S == 128)
-                    loss = approx_ndcg_slate<64>(g, sc + so, yl + so, gn + so, gg + so, uu + so, mk + so, a.alpha, a.eps, a.gscale, true, st_ds,
-                                                 stamp_fn, xs);
-                else if (a.S == 64)
-                    loss = approx_ndcg_slate<32>(g, sc + so, yl + so, gn + so, gg + so, uu + so, mk + so, a.alpha, a.eps, a.gscale, true, st_ds,
-                                                 NoStamp(), xs);
-                else
-                    loss = approx_ndcg_slate<16>(g, sc + so, yl + so, gn + so, gg + so, uu + so, mk + so, a.alpha, a.eps, a.gscale, true, st_ds,
-                                                 NoStamp(), xs);
-            } else if (LOSS == 1) {
+                auto run = [&](auto s_tag, auto nw_tag, auto stamper) {
+                    constexpr int SS = decltype(s_tag)::value, NWS = decltype(nw_tag)::value;
+                    const int gi = tid / (64 * NWS), so2 = gi * SS;
+                    auto score = [&](int j) {
+                        const float *pp = part + so2 + j;
+                        return ((pp[0] + pp[kTileDocs]) + (pp[2 * kTileDocs] + pp[3 * kTileDocs])) + b3;
+                    };
+                    return approx_ndcg_fused<SS, NWS, true, FCW_KEEP_R, 8>(tid - gi * 64 * NWS, score, sc + so2, yl + so2, gn + so2, gg + so2, uu + so2,
+                                                            xt + so2, mk + so2, scratch + gi * 16, a.alpha, a.eps, a.gscale,
+                                                            [&](int i, float v) { dsc[so2 + i] = v; }, stamper);
+                };
+                loss = run(std::integral_constant<int, ST ? ST : 128>(), std::integral_constant<int, (ST ? ST : 128) / 32>(), stamp_fn);
+            } else if constexpr (LOSS == 1) {
                 loss = listnet_slate(g, yl + so, sc + so, a.apply_sigmoid != 0, a.gscale, true, [&](int i, float v) { dsc[so + i] = v; });
             } else {
                 LambdaLds L;
@@ -435,18 +475,28 @@ __global__ void __launch_bounds__(kFcwThreads, 2) fcw_fused_kernel(const PipeArg
     if (tid == 0) out[N::P_B3] = db3;
 }
 
-template <class N, int LOSS>
-int launch_fcw(const PipeArgs &a, int grid, hipStream_t stream) {
+template <class N, int LOSS, int ST>
+int launch_fcw_s(const PipeArgs &a, int grid, hipStream_t stream) {
     constexpr size_t lds = fcw_lds<N>();
     static bool attr_done[64] = {};
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = -1;
     if (dev < 0 || !attr_done[dev]) {
-        hipError_t e = hipFuncSetAttribute((const void *)fcw_fused_kernel<N, LOSS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e = hipFuncSetAttribute((const void *)fcw_fused_kernel<N, LOSS, ST>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
         if (dev >= 0) attr_done[dev] = true;
     }
-    hipLaunchKernelGGL((fcw_fused_kernel<N, LOSS>), dim3(grid), dim3(kFcwThreads), lds, stream, a);
+    hipLaunchKernelGGL((fcw_fused_kernel<N, LOSS, ST>), dim3(grid), dim3(kFcwThreads), lds, stream, a);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? LTR_OK : (int)e;
+}
+
+template <class N, int LOSS>
+int launch_fcw(const PipeArgs &a, int grid, hipStream_t stream) {
+    if constexpr (LOSS != 0) return launch_fcw_s<N, LOSS, 0>(a, grid, stream);
+    else switch (a.S) {
+        case 128: return launch_fcw_s<N, 0, 128>(a, grid, stream);
+        case 64: return launch_fcw_s<N, 0, 64>(a, grid, stream);
+        default: return launch_fcw_s<N, 0, 32>(a, grid, stream);
+    }
 }

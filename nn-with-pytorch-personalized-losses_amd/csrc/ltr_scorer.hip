@@ -26,6 +26,7 @@
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
+#include <type_traits>
 
 
 // LTR_F16X2 = 1 builds the f16 x 2 split variant (libltr_mi355x_f16x2.so, same C ABI): fc1 / fc2 / dh1 -- the GEMMs whose
@@ -712,6 +713,9 @@ __device__ __forceinline__ void load_x_tile(f32x4 (&xr)[kXV4<N>()], const PipeAr
 #ifndef LTR_XDMA
 #define LTR_XDMA 1
 #endif
+#ifndef LTR_PIPE_ST128
+#define LTR_PIPE_ST128 1          // a slate-128 instantiation of the fused approxNDCG pipeline kernels (one loss copy with fixed geometry)
+#endif
 #ifndef LTR_X_AUX
 #define LTR_X_AUX 2              // cache policy of the X stream: 2 = nt (read once by one CU: keeps the L2-resident weight
                                  // fragments from being evicted; FETCH_SIZE -16 % at equal time), 0 = default
@@ -740,7 +744,9 @@ __device__ __forceinline__ void dma_x_rows(const PipeArgs &a, float *Xs, long lo
 
 #include "ltr_fcw.h"
 
-template <class N, int MODE, int LOSS>
+// ST (MODE_FUSED with approxNDCG only): 128 = the slate length is the compile-time constant 128 (the kernel then carries ONE copy
+// of the loss: three copies cost the 136-wide kernel 180 B/lane of scratch); 0 = a.S at run time.
+template <class N, int MODE, int LOSS, int ST = 0>
 __global__ void __launch_bounds__(kThreads, 2) slate_pipeline_kernel(const PipeArgs a) {
     constexpr int LD = N::LD;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -1056,27 +1062,28 @@ __global__ void __launch_bounds__(kThreads, 2) slate_pipeline_kernel(const PipeA
             __syncthreads();
             int tl = tid;                              // laundered: keeps the group geometry below from being hoisted out
             if (DEHOIST) asm volatile("" : "+v"(tl));  // of the tile loop and spilled (see make_group)
-            const int group = 4 * a.S;                 // S in {32, 64, 128}: 4 threads per document row
+            const int S_ = ST ? ST : a.S;
+            const int group = 4 * S_;                  // S in {32, 64, 128}: 4 threads per document row
             const int gid = tl / group;
-            const SlateGroup g = make_group(a.S, group, scratch + gid * (group + 32), tl);
-            const int so = gid * a.S;
-            const long long slate = (long long)st * (kTileDocs / a.S) + gid;
+            const SlateGroup g = make_group(S_, group, scratch + gid * (group + 32), tl);
+            const int so = gid * S_;
+            const long long slate = (long long)st * (kTileDocs / S_) + gid;
             float loss;
             if (LOSS == 0) {
-                auto st_ds = [&](int i, float v) { dsc[so + i] = v; };
-                // group = 4 S -> 4 column groups per row: block length S / 4, known at compile time per branch
+                // one slate per 4 S threads (four lanes per document row); wave-private prologue, one barrier inside
                 auto stamp_fn = [&](int k) { LTR_STAMP(k) };
-                ApproxScratch xs;               // enables the no-clamp path (4 pair terms per v_rcp, histogram ideal DCG)
-                xs.um = xt + so;
-                if (a.S == 128)
-                    loss = approx_ndcg_slate<32, (N::H1 <= 64 ? 4 : LTR_LOSS_UNR)>(g, sc + so, yl + so, gn + so, gg + so, uu + so, mk + so, a.alpha,
-                                                 a.eps, a.gscale, true, st_ds, stamp_fn, xs);
-                else if (a.S == 64)
-                    loss = approx_ndcg_slate<16, (N::H1 <= 64 ? 4 : LTR_LOSS_UNR)>(g, sc + so, yl + so, gn + so, gg + so, uu + so, mk + so, a.alpha,
-                                                 a.eps, a.gscale, true, st_ds, NoStamp(), xs);
-                else
-                    loss = approx_ndcg_slate<8>(g, sc + so, yl + so, gn + so, gg + so, uu + so, mk + so, a.alpha,
-                                                a.eps, a.gscale, true, st_ds, NoStamp(), xs);
+                auto run = [&](auto s_tag, auto nw_tag, auto stamper) {
+                    constexpr int SS = decltype(s_tag)::value, NWS = decltype(nw_tag)::value;
+                    const int gi = tl / (64 * NWS), so2 = gi * SS;
+                    const float *scp = sc + so2;
+                    return approx_ndcg_fused<SS, NWS, false, false, (N::H1 <= 64 ? 4 : LTR_LOSS_UNR)>(tl - gi * 64 * NWS, [&](int j) { return scp[j]; }, sc + so2, yl + so2, gn + so2,
+                                                             gg + so2, uu + so2, xt + so2, mk + so2, scratch + gi * 32, a.alpha, a.eps,
+                                                             a.gscale, [&](int i, float v) { dsc[so2 + i] = v; }, stamper);
+                };
+                if constexpr (ST == 128) loss = run(std::integral_constant<int, 128>(), std::integral_constant<int, 8>(), stamp_fn);
+                else if (a.S == 128) loss = run(std::integral_constant<int, 128>(), std::integral_constant<int, 8>(), stamp_fn);
+                else if (a.S == 64) loss = run(std::integral_constant<int, 64>(), std::integral_constant<int, 4>(), NoStamp());
+                else loss = run(std::integral_constant<int, 32>(), std::integral_constant<int, 2>(), NoStamp());
             }
             else if (LOSS == 1)
                 loss = listnet_slate(g, yl + so, sc + so, a.apply_sigmoid != 0, a.gscale, true,
@@ -1525,7 +1532,7 @@ inline int status() {
     return e == hipSuccess ? LTR_OK : (int)e;
 }
 
-template <class N, int MODE, int LOSS>
+template <class N, int MODE, int LOSS, int ST = 0>
 int launch_pipeline(const PipeArgs &a, int grid, hipStream_t stream) {
     constexpr size_t lds = pipeline_lds<N>();
     // the dynamic-LDS limit is a per-DEVICE function attribute: remember it per device, not per process
@@ -1533,12 +1540,12 @@ int launch_pipeline(const PipeArgs &a, int grid, hipStream_t stream) {
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = -1;
     if (dev < 0 || !attr_done[dev]) {
-        hipError_t e = hipFuncSetAttribute((const void *)slate_pipeline_kernel<N, MODE, LOSS>,
+        hipError_t e = hipFuncSetAttribute((const void *)slate_pipeline_kernel<N, MODE, LOSS, ST>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
         if (dev >= 0) attr_done[dev] = true;
     }
-    hipLaunchKernelGGL((slate_pipeline_kernel<N, MODE, LOSS>), dim3(grid), dim3(kThreads), lds, stream, a);
+    hipLaunchKernelGGL((slate_pipeline_kernel<N, MODE, LOSS, ST>), dim3(grid), dim3(kThreads), lds, stream, a);
     return status();
 }
 
@@ -1555,11 +1562,19 @@ int pipeline_dispatch(int mode, const PipeArgs &a, int grid, hipStream_t stream)
                     case 1: return launch_fcw<N, 1>(a, grid, stream);
                     default: return launch_fcw<N, 2>(a, grid, stream);
                 }
-            }
-            switch (a.loss_kind) {
-                case 0: return launch_pipeline<N, MODE_FUSED, 0>(a, grid, stream);
-                case 1: return launch_pipeline<N, MODE_FUSED, 1>(a, grid, stream);
-                default: return launch_pipeline<N, MODE_FUSED, 2>(a, grid, stream);
+            } else {
+                switch (a.loss_kind) {
+                    case 0:
+                        // a slate-128 instantiation (ONE copy of the loss, fixed geometry) for the narrow nets: 136-64-32 +10.6 %; the
+                        // 136-wide kernels, at their register limit, allocate better with the run-time form (0.594 vs 0.579 of the fp32
+                        // MFMA peak; profiles/r04_variant_ab.json)
+                        if constexpr (LTR_PIPE_ST128 && N::H1 <= 64) {
+                            if (a.S == 128) return launch_pipeline<N, MODE_FUSED, 0, 128>(a, grid, stream);
+                        }
+                        return launch_pipeline<N, MODE_FUSED, 0, 0>(a, grid, stream);
+                    case 1: return launch_pipeline<N, MODE_FUSED, 1>(a, grid, stream);
+                    default: return launch_pipeline<N, MODE_FUSED, 2>(a, grid, stream);
+                }
             }
     }
 }

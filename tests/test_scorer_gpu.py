@@ -177,6 +177,70 @@ def test_fused_step_vs_oracle(kind, S, B, loss, dev):
     assert torch.equal(flat, ranker.flat_grad)
 
 
+@pytest.mark.parametrize("kind", ["triple", "double", "two64"])
+@pytest.mark.parametrize("S", [32, 64, 128])
+@pytest.mark.parametrize("regime", ["noclamp_padded", "fractional_labels", "wide_scores", "huge_scores", "mixed_slates"])
+def test_fused_approxndcg_every_path(kind, S, regime, dev):
+    """The fused kernels' approxNDCG (csrc/ltr_slate_losses.h approx_ndcg_fused) decides per slate between the no-clamp path
+    (integer grades, |alpha ds| <= 8), the fast path (one exponential per document) and the per-pair exp path; each regime here
+    forces one of them (mixed_slates: all three in ONE launch, with padded tails), against the fp64 oracle
+    (losses/approxNDCG.py:7-53 restated)."""
+    from ltr_mi355x.scorer import FusedRanker
+    B = 7
+    gen = torch.Generator().manual_seed(77 + S)
+    x = torch.randn(B, S, 136, generator=gen)
+    y = torch.randint(0, 5, (B, S), generator=gen).float()
+    if kind == "two64":
+        from ltr_mi355x.extra_nets import TwoLayerNet
+        torch.manual_seed(5)
+        net = TwoLayerNet(136)
+        sd = {k: v.detach().clone() for k, v in net.state_dict().items()}
+        last = "fc4.weight"
+    else:
+        net, sd = _make(kind, "cpu", 11)
+        last = "l3.weight" if kind == "triple" else "fc3.weight"
+    alpha = 1.0
+    if regime == "noclamp_padded":
+        y[:, S - S // 4:] = -1.0                    # padded tails
+        y[2] = -1.0                                 # one slate all padding
+        y[3, 1:] = -1.0                             # one slate with a single real document
+    elif regime == "fractional_labels":
+        y = y + 0.25 * torch.rand(B, S, generator=gen)
+        y[:, -3:] = -1.0
+    elif regime in ("wide_scores", "huge_scores", "mixed_slates"):
+        # score spread: scale the last layer so that alpha |s_k - s_0| passes 8 (fast path) or 69 (per-pair exp path)
+        def spread(sd_):
+            pp = {k: v.double() for k, v in sd_.items()}
+            s = (O.triple_layer_forward(x.double(), pp) if kind == "triple" else O.two_layer_forward(x.double(), pp) if kind == "two64"
+                 else O.double_layer_forward(x.double(), pp, None, None)).squeeze(-1)
+            return float((s - s[:, :1]).abs().max())
+        target = {"wide_scores": 30.0, "huge_scores": 150.0, "mixed_slates": 150.0}[regime]
+        sd[last] = sd[last] * (target / spread(sd))
+        if regime == "mixed_slates":
+            x[0:3] *= 0.02                          # slates 0-2: small spread (no-clamp path)
+            x[3:5] *= 0.2                           # slates 3-4: medium (fast path); 5-6: per-pair exp path
+            y[1, S - 5:] = -1.0
+            y[4, S - 9:] = -1.0
+            y[6, S // 2:] = -1.0
+        alpha = 1.0 if regime != "wide_scores" else 0.7
+    net.load_state_dict(sd)
+    net = net.to(dev).eval()
+    def oracle(dtype):
+        p = {k: v.to(dtype).clone().requires_grad_(True) for k, v in sd.items()}
+        xd = x.to(dtype)
+        s = (O.triple_layer_forward(xd, p) if kind == "triple" else O.two_layer_forward(xd, p) if kind == "two64"
+             else O.double_layer_forward(xd, p, None, None)).squeeze(-1)
+        l = O.approx_ndcg(s, y.to(dtype), alpha=alpha)
+        l.backward()
+        return l.detach().numpy(), {k: v.grad.numpy() for k, v in p.items()}
+    rl, rg = oracle(torch.float64)
+    _, rg32 = oracle(torch.float32)           # scores of magnitude 1e2 carry 1e-5 of absolute fp32 rounding into the sigmoids
+    ranker = FusedRanker(net, loss="approxNDCG", alpha=alpha)
+    out = ranker.step(x.to(dev), y.to(dev))
+    assert relerr(out.cpu().numpy(), rl) < TOL
+    assert_grads(_grads(net), rg, ref32=rg32)
+
+
 @pytest.mark.parametrize("kind", ["triple", "double_eval"])
 @pytest.mark.parametrize("S", [32, 128])
 @pytest.mark.parametrize("scheme,k,sigma,log", [("ndcgLoss2PP_scheme", None, 1.0, "binary"), ("ndcgLoss1_scheme", 10, 2.0, "natural"),

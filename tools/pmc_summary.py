@@ -1,0 +1,92 @@
+#!/usr/bin/env python3
+"""rocprofv3 evidence for ONE kernel of ONE command, as a JSON summary (the judge-facing files under profiles/ come from here).
+
+  python3 tools/pmc_summary.py --tag r04_two64 --kernel fcw_fused_kernel [--lib variants/x.so] -- bench.py --net two64 --steps 5 ...
+
+Passes (each its own run of the command, program directly behind `rocprofv3 ... --`, never combined with tracing domains):
+  1. --kernel-trace --stats                      -> calls, average / min / max duration of every matching dispatch
+  2. --kernel-trace --pmc FETCH_SIZE             -> KiB per dispatch   (gfx950: doubled by the reader for wide coalesced reads)
+  3. --kernel-trace --pmc WRITE_SIZE
+  4. --kernel-trace --pmc SQ_INSTS_MFMA SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_LDS_BANK_CONFLICT SQ_WAVES SQ_BUSY_CYCLES
+This process never touches the GPU itself.  Output: gpurun_out/<tag>_pmc.json (+ the raw rocprofv3 directories beside it)."""
+import argparse
+import csv
+import glob
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SQ = ["SQ_INSTS_MFMA", "SQ_INSTS_VALU", "SQ_INSTS_LDS", "SQ_INSTS_SALU", "SQ_WAVE_CYCLES", "SQ_LDS_BANK_CONFLICT", "SQ_WAVES", "SQ_BUSY_CYCLES"]
+
+
+def run(outdir, extra, cmd, env):
+    full = ["rocprofv3", "--kernel-trace"] + extra + ["--output-format", "csv", "-d", outdir, "--", sys.executable] + cmd
+    r = subprocess.run(full, cwd="/tmp", env=env, capture_output=True, text=True, timeout=900)
+    if r.returncode != 0:
+        print("[pmc] FAILED:", " ".join(full), "\n", r.stdout[-1500:], r.stderr[-1500:], flush=True)
+    return r.returncode
+
+
+def rows(outdir, suffix):
+    out = []
+    for f in glob.glob(os.path.join(outdir, "**", "*" + suffix), recursive=True):
+        with open(f) as fh:
+            out += list(csv.DictReader(fh))
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--tag", required=True)
+    ap.add_argument("--kernel", required=True, help="substring of the kernel name")
+    ap.add_argument("--lib", default=None)
+    ap.add_argument("--skip", type=int, default=0, help="ignore the first N matching dispatches (warm-up launches)")
+    ap.add_argument("cmd", nargs=argparse.REMAINDER)
+    a = ap.parse_args()
+    cmd = [c for c in a.cmd if c != "--"]
+    cmd[0] = os.path.join(ROOT, cmd[0])
+    env = dict(os.environ, TMPDIR="/tmp")
+    if a.lib:
+        env["LTR_LIB"] = os.path.join(ROOT, a.lib)
+    base = os.path.join(ROOT, "gpurun_out", a.tag)
+    res = {"command": "python3 " + " ".join(a.cmd[1:] if a.cmd and a.cmd[0] == "--" else a.cmd), "library": a.lib or "default", "kernel_match": a.kernel}
+
+    def pick(rs, key="Kernel_Name"):
+        sel = [r for r in rs if a.kernel in r[key]]
+        return sel[a.skip:] if len(sel) > a.skip else sel
+
+    if run(base + "_trace", ["--stats"], cmd, env) == 0:
+        tr = pick(sorted(rows(base + "_trace", "kernel_trace.csv"), key=lambda r: int(r["Start_Timestamp"])))
+        d = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in tr]
+        if d:
+            res["kernel_trace"] = {"kernel": tr[0]["Kernel_Name"][:160], "dispatches": len(d), "skipped_warmup": a.skip, "avg_us": round(sum(d) / len(d), 2),
+                                   "min_us": round(min(d), 2), "max_us": round(max(d), 2), "vgpr": tr[0].get("VGPR_Count"), "sgpr": tr[0].get("SGPR_Count"),
+                                   "scratch_bytes_per_lane": tr[0].get("Scratch_Size", tr[0].get("Private_Segment_Size")), "lds_bytes": tr[0].get("LDS_Block_Size"),
+                                   "grid": tr[0].get("Grid_Size"), "workgroup": tr[0].get("Workgroup_Size")}
+        st = [r for r in rows(base + "_trace", "kernel_stats.csv") if a.kernel in r["Name"]]
+        if st:
+            res["kernel_stats_csv"] = {"calls": int(st[0]["Calls"]), "avg_us_incl_warmup": round(float(st[0]["AverageNs"]) / 1e3, 2), "pct_of_gpu_time": st[0]["Percentage"]}
+    for name, ctrs in (("FETCH_SIZE", ["FETCH_SIZE"]), ("WRITE_SIZE", ["WRITE_SIZE"]), ("SQ", SQ)):
+        if run(f"{base}_{name}", ["--pmc"] + ctrs, cmd, env) != 0:
+            continue
+        rs = pick(rows(f"{base}_{name}", "counter_collection.csv"))
+        by = {}
+        for r in rs:
+            by.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
+        for k, v in by.items():
+            res.setdefault("pmc_per_dispatch", {})[k] = round(sum(v) / len(v), 1)
+    p = res.get("pmc_per_dispatch", {})
+    if "FETCH_SIZE" in p and "WRITE_SIZE" in p:
+        res["hbm_bytes_per_dispatch"] = int((2.0 * p["FETCH_SIZE"] + p["WRITE_SIZE"]) * 1024)
+        res["hbm_bytes_note"] = "2 x FETCH_SIZE + WRITE_SIZE (KiB): gfx950 counts wide coalesced reads at half their size (MI355X_MICROARCH.md, HBM)"
+    if "SQ_WAVES" in p and p["SQ_WAVES"]:
+        res["per_wave"] = {k: round(p[k] / p["SQ_WAVES"], 1) for k in SQ if k in p and k != "SQ_WAVES"}
+    with open(base + "_pmc.json", "w") as f:
+        json.dump(res, f, indent=1)
+    print(json.dumps(res), flush=True)
+
+
+if __name__ == "__main__":
+    main()
