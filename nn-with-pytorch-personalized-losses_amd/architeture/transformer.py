@@ -110,6 +110,13 @@ class EncoderLayer(nn.Module):
         shape allows)."""
         B = _blocks()
         at, ff = self.self_attn, self.feed_forward
+        # the fused node runs ONE dropout probability at its four sites (attention probabilities, FFN hidden layer, both
+        # residual sublayers) -- what make_model builds (multiLayer.py / transformer.py:240-257).  A layer assembled with different
+        # probabilities takes the composed per-block path, where every module applies its own p like the reference.
+        ps = {float(self.sublayer[0].dropout.p), float(self.sublayer[1].dropout.p), float(at.dropout.p), float(ff.dropout.p)}
+        if len(ps) > 1:
+            x = self.sublayer[0](x, lambda t: at(t, t, t, mask))
+            return self.sublayer[1](x, ff)
         spec = _enc_spec(self.size, 1, at.h, ff.w_1.out_features, self.sublayer[0].dropout.p)
         m = B.slate_mask(mask, x.shape[0], x.shape[1], x.device)
         if m is None:

@@ -169,7 +169,9 @@ inline bool parse_i64(const char *s, const char *t, long long *out) {
     long long v = 0;
     for (; s < t; ++s) {
         if (*s < '0' || *s > '9') return false;
-        v = v * 10 + (*s - '0');
+        const int dgt = *s - '0';
+        if (v > (0x7fffffffffffffffLL - dgt) / 10) return false;      // 19-digit tokens can pass LLONG_MAX: reject, never overflow
+        v = v * 10 + dgt;
     }
     *out = neg ? -v : v;
     return true;

@@ -349,7 +349,9 @@ risk_matrix_kernel(const float *__restrict__ ref, const float *__restrict__ x0, 
         // cosine operands: (u, v) = (t, x) [modes 0, 1] or (t^2, t x) [mode 2]
         const double ca = mode == 2 ? mat_block_sum(ac_a, red) : a, cnu = mode == 2 ? mat_block_sum(nu_a, red) : nt,
                      cnv = mode == 2 ? mat_block_sum(nv_a, red) : nx;
-        const double den2 = cnu * cnv > 1e-16 ? cnu * cnv : 1e-16, den = sqrt(den2);
+        // torch.nn.CosineSimilarity (riskLosses.py: nn.CosineSimilarity(dim=1), eps = 1e-8) clamps EACH norm: u . v / (max(|u|, eps) max(|v|, eps))
+        const double nrm_u = sqrt(cnu), nrm_v = sqrt(cnv);
+        const double den = (nrm_u > 1e-8 ? nrm_u : 1e-8) * (nrm_v > 1e-8 ? nrm_v : 1e-8);
         double m;
         if (lt == 1) m = c;
         else if (lt == 2) m = ca / den;
@@ -357,7 +359,7 @@ risk_matrix_kernel(const float *__restrict__ ref, const float *__restrict__ x0, 
         if (tid == 0) mat[(size_t)b * nsys + sys] = (float)m;
         if (sys == 0 && jac) {
             // g_j = d m / d x_j; mode 0: x = softmax(s): d m / d s_j = x_j (g_j - sum_k x_k g_k)
-            const bool clamped = !(cnu * cnv > 1e-16);
+            const bool clamped = !(nrm_v > 1e-8);       // |v| below eps: the clamp passes no gradient to the norm, d m / d v = u / den
             auto grad = [&](int j) -> double {
                 const double tj = t[j], xj = x[j];
                 if (lt == 1) return mode == 1 ? 2.0 * (xj - tj) : 2.0 * tj * (tj * xj - tj * tj);

@@ -76,7 +76,9 @@ class Features(torch.autograd.Function):
             if final_norm:
                 prm = st["prm"]
                 _, out = E.layernorm_fwd(out, prm[-2], prm[-1], B * S, spec.d_model, E.LN_EPS, 0, want_f32=True)
-            elif out is st["xin"]:
+            else:
+                # the residual stream's last tensor stays in ctx.st for the backward (outside save_for_backward, so no version
+                # counter guards it): hand out a copy, an in-place edit of the output must not reach it
                 out = out.clone()
         ctx.st = st
         return out.view(B, S, spec.d_model)

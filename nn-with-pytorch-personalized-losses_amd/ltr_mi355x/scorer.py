@@ -318,9 +318,19 @@ class FusedRanker:
         """Second half of the deferred-normalisation protocol: divide [grads | loss] by the (all-reduced) normaliser.
         Device ops only.  0 / 0 = nan is the reference's "mean of nothing"."""
         if self.mean_kind is not None:
-            self.flat.div_(self._norm)
+            self._divide_by_norm()
         self._bind_grads()
         return self._loss_out
+
+    def _divide_by_norm(self):
+        """[grads | loss] /= normaliser, as device ops (no host read).  An EMPTY mean -- no kept pair anywhere (every slate with
+        uniform labels, all ranks empty under data parallel) -- leaves a nan LOSS and ZERO gradients, like the reference
+        (lambdaL.py:88-89: torch.mean of an empty selection is nan, its autograd gradient is zeros): the loss slot is divided by
+        the raw count (0 / 0 = nan), the gradient slice by the count with 0 replaced by 1 (the sum-form gradients are exactly
+        zero then) -- never 0 / 0 into a tensor the optimizer steps on."""
+        n = self._norm
+        self.flat_grad.div_(torch.where(n > 0, n, torch.ones_like(n)))
+        self.flat[self.info.n_params:].div_(n)
 
     def step(self, X, y, world_batch=None, keep1=None, keep2=None, seed=None, train=None, defer_norm=False):
         """Run the fused pass on this rank's slates.  Returns the 0-dim LOCAL loss contribution, already
@@ -406,7 +416,7 @@ class FusedRanker:
                 # [grads | loss] by the kept-pair count follows (here, or after the all-reduce when deferred)
                 torch.sum(count, dim=0, keepdim=True, out=self._norm)
                 if not defer_norm:
-                    self.flat.div_(self._norm)
+                    self._divide_by_norm()
         self._bind_grads()
         return self._loss_out
 
@@ -448,5 +458,5 @@ class FusedRanker:
         if lambda_mean:
             torch.sum(count, dim=0, keepdim=True, out=self._norm)
             if not defer_norm:
-                self.flat.div_(self._norm)
+                self._divide_by_norm()
         return self._loss_out

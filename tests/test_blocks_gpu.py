@@ -190,3 +190,37 @@ def test_blocks_train_mode_and_errors():
         T.LayerNorm(32)(x.cpu())
     ff = T.PositionwiseFeedForward(32, 64, 0.5).to(DEV).train()
     assert not torch.equal(ff(x), ff(x))
+
+
+def test_encoder_layer_with_mixed_dropout_probabilities_takes_the_composed_path():
+    """An EncoderLayer whose four dropout modules carry DIFFERENT probabilities (attention, FFN hidden, the two residual
+    sublayers; the reference applies each module's own p, transformer.py:106-142) must not run the fused node with one p: it
+    walks the composed per-block path.  In eval mode (no dropout active) both paths compute the same function; in training
+    mode the composed path's outputs differ between two calls only through dropout -- and with every p = 0 they are identical."""
+    from architeture import transformer as T
+    torch.manual_seed(3)
+    d, h, dff = 64, 4, 128
+    mixed = T.EncoderLayer(d, T.MultiHeadedAttention(h, d, 0.3), T.PositionwiseFeedForward(d, dff, 0.05), 0.2).to(DEV)
+    mixed.sublayer[1].dropout.p = 0.4
+    uniform = T.EncoderLayer(d, T.MultiHeadedAttention(h, d, 0.1), T.PositionwiseFeedForward(d, dff, 0.1), 0.1).to(DEV)
+    uniform.load_state_dict(mixed.state_dict())
+    x = torch.randn(3, 40, d, device=DEV)
+    mask = torch.zeros(3, 40, dtype=torch.bool, device=DEV)
+    mask[1, 30:] = True
+    mixed.eval(), uniform.eval()
+    a, b = mixed(x, mask), uniform(x, mask)
+    assert relerr(a.detach().cpu().numpy(), b.detach().cpu().numpy()) < 2e-2            # bf16 operands on both paths
+    mixed.train()
+    xg = x.clone().requires_grad_(True)
+    out = mixed(xg, mask)
+    out.square().mean().backward()
+    assert torch.isfinite(out).all() and torch.isfinite(xg.grad).all()
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in mixed.parameters())
+    # the fused node hands out a copy of its residual stream: an in-place edit of the output must not corrupt the backward
+    uniform.train(False)
+    xg2 = x.clone().requires_grad_(True)
+    o2 = uniform(xg2, mask)
+    ref = torch.autograd.grad(o2.sum(), xg2, retain_graph=True)[0].clone()
+    o2.detach().zero_()
+    again = torch.autograd.grad(o2.sum(), xg2)[0]
+    assert torch.equal(ref, again)

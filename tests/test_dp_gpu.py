@@ -307,17 +307,37 @@ def test_make_model_two_ranks_equal_single_process():
     # of the backward see differently scaled values (2^-9 each) -- the bf16 bar of tests/test_encoder_gpu.py applies.
     upd = [(a - i0, c.detach().cpu() - i0) for a, c, i0 in zip(r0["params"], net.parameters(), init)]
     top = max(float(u.abs().max()) for _, u in upd)
-    # Bars: the measured bf16 self-noise of this scorer family (tests/test_encoder_gpu.py::_oracle_gate: an fp32-vs-fp64 run
-    # of the rounding-faithful oracle moves single entries by up to ~5e-2 of the tensor's scale, L2 by ~1e-2), doubled
-    # because BOTH sides here are bf16 runs: max-norm 1.5e-1, L2 5e-2 per tensor, and the whole update vector within
-    # cosine 0.999 -- a missing all-reduce or a wrong 1/B shows as a factor 2 in the L2 figure.
+    # Bars per tensor: max-norm 5e-2 and L2 5e-2 of the tensor's scale.  Both sides are bf16 runs whose backward roundings see
+    # differently scaled values, so SINGLE entries of a tensor can sit further out (the rounding-faithful oracle's fp32-vs-fp64
+    # self-test moves single entries by up to ~5e-2 on one side alone, tests/test_encoder_gpu.py::_oracle_gate): a tensor may
+    # exceed 5e-2 only as an OUTLIER -- at most 1 % of its entries (never more than 8) above 5e-2, none above 1.5e-1, its L2 still
+    # inside 5e-2 -- at most three such tensors, and each is named in the ledger.  A missing all-reduce or a wrong 1/B moves EVERY
+    # entry (a factor 2 in the L2 figure).
+    names = [k for k, _ in net.named_parameters()]
     worst_max = worst_l2 = 0.0
-    for (ua, uc), a, b in zip(upd, r0["params"], r1["params"]):
+    outliers = []
+    for name, (ua, uc), a, b in zip(names, upd, r0["params"], r1["params"]):
         assert torch.equal(a, b)
-        worst_max = max(worst_max, float((ua - uc).abs().max()) / max(float(uc.abs().max()), 0.05 * top))
-        worst_l2 = max(worst_l2, float((ua - uc).norm()) / max(float(uc.norm()), 0.05 * top * ua.numel() ** 0.5))
+        scale = max(float(uc.abs().max()), 0.05 * top)
+        dev_abs = (ua - uc).abs()
+        mx = float(dev_abs.max()) / scale
+        l2 = float((ua - uc).norm()) / max(float(uc.norm()), 0.05 * top * ua.numel() ** 0.5)
+        worst_max, worst_l2 = max(worst_max, mx), max(worst_l2, l2)
+        assert l2 < 5e-2, (name, l2)
+        if mx >= 5e-2:
+            n_over = int((dev_abs > 5e-2 * scale).sum())
+            outliers.append({"tensor": name, "max_norm": mx, "entries_over_5e-2": n_over, "entries": ua.numel(), "l2": l2})
+            assert mx < 1.5e-1 and n_over <= max(1, min(8, ua.numel() // 100)), outliers[-1]
+    assert len(outliers) <= 3, outliers
+    try:
+        from conftest import ledger_record
+        for o in outliers:
+            ledger_record(f"dp make_model update[{o['tensor']}] max-norm outlier ({o['entries_over_5e-2']} of {o['entries']} entries over 5e-2)",
+                          o["max_norm"], None, 5e-2, note="bf16 rounding outlier: L2 inside 5e-2")
+    except Exception:
+        pass
     fa, fc = torch.cat([u.flatten() for u, _ in upd]).double(), torch.cat([u.flatten() for _, u in upd]).double()
     cos = float(fa @ fc / (fa.norm() * fc.norm()))
     print(f"[dp make_model] worst max-norm {worst_max:.3e}  worst L2 {worst_l2:.3e}  cosine {cos:.6f}  |a|/|c| {float(fa.norm() / fc.norm()):.5f}")
-    assert worst_max < 1.5e-1 and worst_l2 < 5e-2, (worst_max, worst_l2)
+    print(f"[dp make_model] tensors above 5e-2 max-norm (outlier entries only): {outliers}")
     assert cos > 0.999 and abs(float(fa.norm() / fc.norm()) - 1) < 2e-2

@@ -138,6 +138,37 @@ def test_lambda_k0_keeps_nothing(S, red, dev):
     assert (float(l) == 0.0) if red == "sum" else bool(torch.isnan(l))
 
 
+@pytest.mark.parametrize("S", [128, 50])
+@pytest.mark.parametrize("protocol", ["step", "deferred", "trainer"])
+def test_lambda_mean_of_no_pairs_gives_nan_loss_and_zero_gradients(S, protocol, dev):
+    """reduction="mean" when NO pair is kept (every slate with uniform labels): the reference's torch.mean of an empty selection is
+    nan and its gradient is zeros (lambdaL.py:88-89).  The pair count is only known on the device: the division must not turn the
+    (exactly zero) sum-form gradients into 0 / 0 = nan for the optimizer -- on the direct path, the deferred-normalisation protocol
+    and through QueryShardedTrainer (which steps the optimizer)."""
+    from ltr_mi355x.dp import QueryShardedTrainer
+    from ltr_mi355x.scorer import FusedRanker
+    net, _ = _make("triple", dev, 5)
+    gen = torch.Generator().manual_seed(S)
+    x = torch.randn(3, S, 136, generator=gen).to(dev)
+    y = torch.full((3, S), 2.0, device=dev)               # uniform labels: no pair with y_i > y_j
+    y[1] = 0.0
+    ranker = FusedRanker(net, loss="lambdaLoss", weighing_scheme="ndcgLoss2PP_scheme", reduction="mean")
+    before = [p.detach().clone() for p in net.parameters()]
+    ranker.flat.fill_(7.0)
+    if protocol == "step":
+        out = ranker.step(x, y)
+    elif protocol == "deferred":
+        ranker.step(x, y, defer_norm=True)
+        out = ranker.finish_norm()
+    else:
+        opt = torch.optim.SGD(net.parameters(), lr=0.1)
+        out = QueryShardedTrainer(ranker, opt).step(x, y)
+    assert bool(torch.isnan(out))
+    assert float(ranker.flat_grad.abs().max()) == 0.0 and not bool(torch.isnan(ranker.flat_grad).any())
+    for p, b in zip(net.parameters(), before):
+        assert torch.equal(p.detach(), b)                 # a nan gradient would have destroyed the weights
+
+
 @pytest.mark.parametrize("order", ["zero_after_step", "zero_before_step", "module_zero_grad"])
 def test_fused_ranker_survives_zero_grad(order, dev):
     """opt.zero_grad() defaults to set_to_none=True and drops the p.grad -> flat-buffer aliasing; the reference loop

@@ -163,6 +163,35 @@ def test_fused_risk_matrix_matches_the_tensor_algebra_path(B, S, nb, lt, ideal, 
         assert relerr(c.grad.cpu().numpy(), c64.grad.cpu().numpy()) < 1e-5
 
 
+@pytest.mark.parametrize("ideal", [False, True])
+def test_fused_risk_matrix_cosine_of_a_zero_vector(ideal, dev):
+    """Cosine effectiveness (mode 1: Lambda-type column sums) when one query's model vector is all zeros: F.cosine_similarity of the
+    installed torch clamps EACH norm at eps = 1e-8 (x / max(|x|, eps)), not the product -- the value is 0 and the gradient w.r.t.
+    the zero vector is ref / (|ref| eps); a near-zero vector (norm 3e-9 < eps) takes the same clamped branch."""
+    from losses.riskLosses import riskLosses as RL
+    from ltr_mi355x import risk as R
+    gen = torch.Generator().manual_seed(11)
+    B, S, nb = 5, 24, 2
+    tt, rest = torch.rand(B, S, generator=gen).to(dev), torch.rand(nb, B, S, generator=gen).to(dev)
+    c0 = torch.rand(B, S, generator=gen)
+    c0[1] = 0.0
+    c0[3] = 0.0
+    c0[3, 5] = 3e-9
+    rest[1, 2] = 0.0                                   # a baseline with a zero vector too (no gradient flows there)
+    c = c0.to(dev).requires_grad_(True)
+    w = torch.randn(B, 1 + nb + int(ideal), generator=gen).to(dev)
+    m1 = R.risk_matrix(tt, c, rest, 1, 2, ideal)
+    (m1 * w).sum().backward()
+    c64 = c0.double().to(dev).requires_grad_(True)
+    parts = [c64.unsqueeze(0), rest.double()] + ([tt.double().unsqueeze(0)] if ideal else [])
+    r1 = RL._effectiveness(tt.double(), torch.cat(parts, 0), 2).t()
+    (r1 * w.double()).sum().backward()
+    assert float(m1[1, 0]) == 0.0 and float(m1[2, 2]) == 0.0
+    assert relerr(m1.detach().cpu().numpy(), r1.detach().cpu().numpy()) < 2e-6
+    for b in range(B):                                 # per query: the clamped rows carry gradients of 1e8, the others of 1
+        assert relerr(c.grad[b].cpu().numpy(), c64.grad[b].cpu().numpy()) < 1e-5, b
+
+
 @pytest.mark.parametrize("Q,n", [(2, 2), (100, 5), (37, 1), (2000, 4)])
 @pytest.mark.parametrize("kind", ["geo", "z"])
 @pytest.mark.parametrize("strategy", [1, 2, 3])
