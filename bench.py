@@ -249,14 +249,20 @@ def main():
         step(i)
     # --- timed region: barrier + synchronize on both sides, max over ranks
     evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(a.steps)]
+    cevs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(a.steps)] if world > 1 else None
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(a.steps):
         ranker.kernel_events = evs[i]
+        if cevs:
+            trainer.comm_events = cevs[i]
         loss = step(a.warmup + i)
     ranker.kernel_events = None
+    trainer.comm_events = None
+    torch.cuda.synchronize()
+    dt_local = time.perf_counter() - t0          # this rank's own clock over the K steps (before the closing barrier)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -266,6 +272,17 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
     dt = float(tt)
     kern_ms = sum(s.elapsed_time(e) for s, e in evs) / a.steps
+    # per rank: its own step time, its pipeline-kernel time and the time of the ONE all-reduce per step (HIP events on the stream the
+    # collective is enqueued on) -- so that a 1/2/4/8 curve can be read: where a rank's step exceeds kernel + Adam, the collective
+    # (or waiting for the slowest rank inside it) is the difference
+    comm_ms = sum(s.elapsed_time(e) for s, e in cevs) / a.steps if cevs else 0.0
+    mine = torch.tensor([dt_local / a.steps * 1e3, kern_ms, comm_ms], dtype=torch.float64, device=dev)
+    per_rank = [mine]
+    if world > 1:
+        per_rank = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(per_rank, mine)
+    print(json.dumps({"rank": rank, "ms_per_step_local": round(float(mine[0]), 4), "kernel_ms": round(float(mine[1]), 4),
+                      "allreduce_ms": round(float(mine[2]), 4)}), file=sys.stderr, flush=True)
     one_launch = S in (32, 64, 128)
     if not one_launch:
         # three-launch path: the bracketed backward launch is only part of the work (it recomputes the forward),
@@ -291,6 +308,9 @@ def main():
                                    f"{'one fused launch (fwd+loss+bwd)' if S in (32, 64, 128) else 'forward launch + loss kernel + backward launch'}"
                                    " + grad all-reduce + Adam",
                        "queries_per_gpu": Q, "slate": S, "features": F, "batch_per_gpu": B, "net": a.net,
+                       "resident_GB_per_gpu": round(Q * S * (F + 1) * 4 / 1e9, 2), "step_windows": n_win,
+                       "step_windows_visited": min(n_win, a.warmup + a.steps),
+                       "last_window_starts_at_float": int(((min(n_win, a.warmup + a.steps) - 1) % n_win) * B) * S * F,
                        "parallelism": f"query-sharded dp{world}", "final_loss": round(final_loss, 6)},
             "roofline": {"bound": "mfma", "achieved": round(ach_tf, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(ach_tf / PEAK_F32_MFMA_TFLOPS, 4),
@@ -302,6 +322,8 @@ def main():
                          "hbm_achieved_GBps": round(ach_gb, 1), "hbm_frac_of_8TBps": round(ach_gb / PEAK_HBM_GBPS, 4),
                          "hbm_frac_of_measured_copy": round(ach_gb / PEAK_HBM_MEASURED_GBPS, 4)},
         }
+        out["per_rank"] = [{"rank": r, "ms_per_step_local": round(float(t[0]), 4), "kernel_ms": round(float(t[1]), 4),
+                            "allreduce_ms": round(float(t[2]), 4)} for r, t in enumerate(per_rank)]
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(a.net, S)
         if world == 1 and not a.no_extras and not a.no_cpu_baseline and a.net == "double" and a.loss == "approxNDCG" \

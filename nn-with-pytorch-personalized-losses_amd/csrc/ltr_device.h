@@ -11,6 +11,17 @@
 #include <stdint.h>
 
 #define LTR_WAVE 64
+
+// Launch grids.  A dispatch's grid is counted in WORK-ITEMS per dimension in 32 bits: blocks x threads-per-block >= 2^32 in x is
+// truncated silently (17 M slates x 256 threads already pass it -- found by tests/test_large_shard_gpu.py).  Kernels whose block count
+// scales with the batch take their linear block id from ltr_block_id() and are launched with ltr_grid(blocks): x <= 2^20 blocks
+// (x 1024 threads = 2^30 work-items), the rest in y; blocks past the end see an id >= the count and must idle through.
+#define LTR_GRID_X_MAX (1ll << 20)
+__device__ __forceinline__ long long ltr_block_id() { return (long long)blockIdx.y * gridDim.x + blockIdx.x; }
+inline dim3 ltr_grid(long long blocks) {
+    if (blocks <= LTR_GRID_X_MAX) return dim3((unsigned)(blocks > 0 ? blocks : 1));
+    return dim3((unsigned)LTR_GRID_X_MAX, (unsigned)((blocks + LTR_GRID_X_MAX - 1) / LTR_GRID_X_MAX));
+}
 #define LTR_LN2 0.69314718055994530942f
 
 namespace ltr {

@@ -55,7 +55,7 @@ approxndcg_kernel(const float *__restrict__ scores, const float *__restrict__ la
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int s_al = (S + 3) & ~3;
     const int gid = threadIdx.x / group;
-    const int slate = blockIdx.x * (blockDim.x / group) + gid;
+    const long long slate = ltr_block_id() * (blockDim.x / group) + gid;
     const bool active = slate < B;
     float *base = smem + (size_t)gid * (kApproxArrays * s_al + group + 32);
     float *sc = base, *yl = sc + s_al, *gn = yl + s_al, *gg = gn + s_al, *uu = gg + s_al, *mk = uu + s_al;
@@ -83,7 +83,7 @@ listnet_kernel(const float *__restrict__ y_true, const float *__restrict__ y_pre
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int s_al = (S + 3) & ~3;
     const int gid = threadIdx.x / group;
-    const int slate = blockIdx.x * (blockDim.x / group) + gid;
+    const long long slate = ltr_block_id() * (blockDim.x / group) + gid;
     const bool active = slate < B;
     float *base = smem + (size_t)gid * (2 * s_al + group + 32);
     float *yt = base, *yp = yt + s_al;
@@ -123,7 +123,7 @@ lambda_kernel(const float *__restrict__ scores, const float *__restrict__ labels
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int s_al = (S + 3) & ~3;
     const int gid = threadIdx.x / group;
-    const int slate = blockIdx.x * (blockDim.x / group) + gid;
+    const long long slate = ltr_block_id() * (blockDim.x / group) + gid;
     const bool active = slate < B;
     float *base = smem + (size_t)gid * (kLambdaArrays * s_al + group + 32);
     const LambdaLds L = lambda_carve(base, s_al);
@@ -154,7 +154,8 @@ lambda_blocked_kernel(const float *__restrict__ scores, const float *__restrict_
                       float *__restrict__ dscores) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int s_al = (S + 3) & ~3, s64 = (S + 63) & ~63;
-    const int slate = blockIdx.x;
+    const long long slate = ltr_block_id();
+    if (slate >= B) return;                      // (whole block: the y-padding of a two-dimensional grid)
     const LambdaLds L = lambda_carve(smem, s_al);
     float *rb = smem + kLambdaArrays * s_al;
     LambdaRankLds R;
@@ -190,7 +191,8 @@ lambda_pairs_fwd_kernel(const float *__restrict__ scores, const float *__restric
                         uint8_t *__restrict__ keep, int32_t *__restrict__ rank) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int s_al = (S + 3) & ~3;
-    const int slate = blockIdx.x;
+    const long long slate = ltr_block_id();
+    if (slate >= B) return;                      // (whole block: the y-padding of a two-dimensional grid)
     float *base = smem;
     const LambdaLds L = lambda_carve(base, s_al);
     int *dar = reinterpret_cast<int *>(base + kLambdaArrays * s_al);   // document at rank r
@@ -238,7 +240,8 @@ lambda_colsum_fwd_kernel(const float *__restrict__ scores, const float *__restri
                          int group, LambdaParams P, float pad, float *__restrict__ colsum) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int s_al = (S + 3) & ~3;
-    const int slate = blockIdx.x;
+    const long long slate = ltr_block_id();
+    if (slate >= B) return;                      // (whole block: the y-padding of a two-dimensional grid)
     float *base = smem;
     const LambdaLds L = lambda_carve(base, s_al);
     int *dar = reinterpret_cast<int *>(base + kLambdaArrays * s_al);   // document at rank r
@@ -283,7 +286,8 @@ lambda_pairs_bwd_kernel(const float *__restrict__ scores, const float *__restric
                         float *__restrict__ dscores) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int s_al = (S + 3) & ~3;
-    const int slate = blockIdx.x;
+    const long long slate = ltr_block_id();
+    if (slate >= B) return;                      // (whole block: the y-padding of a two-dimensional grid)
     float *base = smem;
     const LambdaLds L = lambda_carve(base, s_al);
     const SlateGroup g = make_group(S, group, base + kLambdaArrays * s_al);
@@ -335,7 +339,8 @@ __global__ void __launch_bounds__(kOrdBlock)
 ordinal_kernel(const float *__restrict__ y_pred, const float *__restrict__ y_true, int64_t n_docs, int n,
                float pad, float *__restrict__ block_partials, float *__restrict__ dpred) {
     __shared__ float red[2 * (kOrdBlock / LTR_WAVE)];
-    const int64_t doc = (int64_t)blockIdx.x * kOrdBlock + threadIdx.x;
+    if (ltr_block_id() * kOrdBlock >= n_docs) return;             // (whole block: the y-padding of a two-dimensional grid)
+    const int64_t doc = ltr_block_id() * kOrdBlock + threadIdx.x;
     float ls = 0.f, nv = 0.f;
     if (doc < n_docs) {
         const float y = y_true[doc];
@@ -371,8 +376,8 @@ ordinal_kernel(const float *__restrict__ y_pred, const float *__restrict__ y_tru
             a += red[2 * i];
             b += red[2 * i + 1];
         }
-        block_partials[2 * (int64_t)blockIdx.x] = a;
-        block_partials[2 * (int64_t)blockIdx.x + 1] = b;
+        block_partials[2 * ltr_block_id()] = a;
+        block_partials[2 * ltr_block_id() + 1] = b;
     }
 }
 
@@ -477,7 +482,7 @@ int ltr_approxndcg_fwd_bwd(const float *scores, const float *labels, int B, int 
     if (B == 0) return LTR_OK;
     const SlateLaunch L = plan(B, S, kApproxArrays);
     if (int rc = allow_lds(approxndcg_kernel, L.lds)) return rc;
-    hipLaunchKernelGGL(approxndcg_kernel, dim3(L.grid), dim3(L.block), L.lds, (hipStream_t)stream, scores, labels,
+    hipLaunchKernelGGL(approxndcg_kernel, ltr_grid(L.grid), dim3(L.block), L.lds, (hipStream_t)stream, scores, labels,
                        B, S, L.group, alpha, eps, pad, grad_scale, slate_loss, dscores);
     return launch_status();
 }
@@ -493,7 +498,7 @@ int ltr_listnet_fwd_bwd(const float *y_true, const float *y_pred, int B, int S, 
     L.gpb = L.block / L.group;
     L.grid = (B + L.gpb - 1) / L.gpb;
     L.lds = (size_t)L.gpb * (2 * ((S + 3) & ~3) + L.group + 32) * sizeof(float);
-    hipLaunchKernelGGL(listnet_kernel, dim3(L.grid), dim3(L.block), L.lds, (hipStream_t)stream, y_true, y_pred, B,
+    hipLaunchKernelGGL(listnet_kernel, ltr_grid(L.grid), dim3(L.block), L.lds, (hipStream_t)stream, y_true, y_pred, B,
                        S, L.group, apply_sigmoid, grad_scale, slate_loss, dscores);
     return launch_status();
 }
@@ -511,7 +516,7 @@ int ltr_lambda_fwd_bwd(const float *scores, const float *labels, int B, int S, i
         const size_t lds = (size_t)(kLambdaArrays * s_al + 5 * s64 + s64 + 32) * sizeof(float);
 #define CALLB(SCH)                                                                                                \
     if (int rc = allow_lds(lambda_blocked_kernel<SCH>, lds)) return rc;                                           \
-    hipLaunchKernelGGL(lambda_blocked_kernel<SCH>, dim3(B), dim3(s64), lds, (hipStream_t)stream, scores, labels,  \
+    hipLaunchKernelGGL(lambda_blocked_kernel<SCH>, ltr_grid(B), dim3(s64), lds, (hipStream_t)stream, scores, labels,  \
                        B, S, P, pad, grad_scale, slate_loss, slate_count, dscores)
         switch (scheme) {
             case 0: { CALLB(0); break; }
@@ -528,7 +533,7 @@ int ltr_lambda_fwd_bwd(const float *scores, const float *labels, int B, int S, i
     const SlateLaunch L = plan(B, S, kLambdaArrays);
 #define CALL(SCH)                                                                                                 \
     if (int rc = allow_lds(lambda_kernel<SCH>, L.lds)) return rc;                                                 \
-    hipLaunchKernelGGL(lambda_kernel<SCH>, dim3(L.grid), dim3(L.block), L.lds, (hipStream_t)stream, scores,       \
+    hipLaunchKernelGGL(lambda_kernel<SCH>, ltr_grid(L.grid), dim3(L.block), L.lds, (hipStream_t)stream, scores,       \
                        labels, B, S, L.group, P, pad, grad_scale, slate_loss, slate_count, dscores)
     LTR_DISPATCH_SCHEME(scheme, CALL)
 #undef CALL
@@ -546,7 +551,7 @@ int ltr_lambda_pairs_fwd(const float *scores, const float *labels, int B, int S,
     const size_t lds = (size_t)((kLambdaArrays + 1) * ((S + 3) & ~3) + group + 32) * sizeof(float);
 #define CALL(SCH)                                                                                                 \
     if (int rc = allow_lds(lambda_pairs_fwd_kernel<SCH>, lds)) return rc;                                         \
-    hipLaunchKernelGGL(lambda_pairs_fwd_kernel<SCH>, dim3(B), dim3(group), lds, (hipStream_t)stream, scores,      \
+    hipLaunchKernelGGL(lambda_pairs_fwd_kernel<SCH>, ltr_grid(B), dim3(group), lds, (hipStream_t)stream, scores,      \
                        labels, B, S, group, P, pad, losses, keep, rank)
     LTR_DISPATCH_SCHEME(scheme, CALL)
 #undef CALL
@@ -565,7 +570,7 @@ int ltr_lambda_pairs_bwd(const float *scores, const float *labels, int B, int S,
     const size_t lds = (size_t)(kLambdaArrays * ((S + 3) & ~3) + group + 32) * sizeof(float);
 #define CALL(SCH)                                                                                                 \
     if (int rc = allow_lds(lambda_pairs_bwd_kernel<SCH>, lds)) return rc;                                         \
-    hipLaunchKernelGGL(lambda_pairs_bwd_kernel<SCH>, dim3(B), dim3(group), lds, (hipStream_t)stream, scores,      \
+    hipLaunchKernelGGL(lambda_pairs_bwd_kernel<SCH>, ltr_grid(B), dim3(group), lds, (hipStream_t)stream, scores,      \
                        labels, B, S, group, P, pad, grad_losses, 0, dscores)
     LTR_DISPATCH_SCHEME(scheme, CALL)
 #undef CALL
@@ -582,7 +587,7 @@ int ltr_lambda_colsum_fwd(const float *scores, const float *labels, int B, int S
     const size_t lds = (size_t)((kLambdaArrays + 1) * ((S + 3) & ~3) + group + 32) * sizeof(float);
 #define CALL(SCH)                                                                                                 \
     if (int rc = allow_lds(lambda_colsum_fwd_kernel<SCH>, lds)) return rc;                                        \
-    hipLaunchKernelGGL(lambda_colsum_fwd_kernel<SCH>, dim3(B), dim3(group), lds, (hipStream_t)stream, scores,     \
+    hipLaunchKernelGGL(lambda_colsum_fwd_kernel<SCH>, ltr_grid(B), dim3(group), lds, (hipStream_t)stream, scores,     \
                        labels, B, S, group, P, pad, colsum)
     LTR_DISPATCH_SCHEME(scheme, CALL)
 #undef CALL
@@ -601,7 +606,7 @@ int ltr_lambda_colsum_bwd(const float *scores, const float *labels, int B, int S
     const size_t lds = (size_t)(kLambdaArrays * ((S + 3) & ~3) + group + 32) * sizeof(float);
 #define CALL(SCH)                                                                                                 \
     if (int rc = allow_lds(lambda_pairs_bwd_kernel<SCH>, lds)) return rc;                                         \
-    hipLaunchKernelGGL(lambda_pairs_bwd_kernel<SCH>, dim3(B), dim3(group), lds, (hipStream_t)stream, scores,      \
+    hipLaunchKernelGGL(lambda_pairs_bwd_kernel<SCH>, ltr_grid(B), dim3(group), lds, (hipStream_t)stream, scores,      \
                        labels, B, S, group, P, pad, grad_colsum, 1, dscores)
     LTR_DISPATCH_SCHEME(scheme, CALL)
 #undef CALL
@@ -616,7 +621,7 @@ int ltr_ordinal_fwd_bwd(const float *y_pred, const float *y_true, int64_t n_docs
     if (n_docs < 0 || n < 1 || n > 64 || ltr_ordinal_num_blocks(n_docs) > 0x7fffffff) return LTR_ERR_SHAPE;
     const int64_t nb = ltr_ordinal_num_blocks(n_docs);
     if (nb > 0) {
-        hipLaunchKernelGGL(ordinal_kernel, dim3((unsigned)nb), dim3(kOrdBlock), 0, (hipStream_t)stream, y_pred,
+        hipLaunchKernelGGL(ordinal_kernel, ltr_grid(nb), dim3(kOrdBlock), 0, (hipStream_t)stream, y_pred,
                            y_true, n_docs, n, pad, block_partials, dpred);
         if (int rc = launch_status()) return rc;
     }

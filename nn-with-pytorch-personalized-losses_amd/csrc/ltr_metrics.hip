@@ -30,7 +30,8 @@ ndcg_kernel(const float *__restrict__ y_true, const float *__restrict__ y_score,
     extern __shared__ __attribute__((aligned(16))) float smem[];
     __shared__ double red[2 * 16];
     float *y = smem, *s = smem + S;
-    const int q = blockIdx.x;
+    const long long q = ltr_block_id();
+    if (q >= Q) return;
     const size_t off = (size_t)q * S;
     for (int j = threadIdx.x; j < S; j += blockDim.x) {
         y[j] = y_true[off + j];
@@ -87,7 +88,7 @@ int ltr_ndcg_at_k(const float *y_true, const float *y_score, int Q, int S, int k
         hipError_t e = hipFuncSetAttribute((const void *)ndcg_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
     }
-    hipLaunchKernelGGL(ndcg_kernel, dim3(Q), dim3(block), lds, (hipStream_t)stream, y_true, y_score, Q, S, k,
+    hipLaunchKernelGGL(ndcg_kernel, ltr_grid(Q), dim3(block), lds, (hipStream_t)stream, y_true, y_score, Q, S, k,
                        gains == LTR_GAINS_EXPONENTIAL ? 1 : 0, no_relevant ? 1.0 : 0.0, reverse_ties ? 1 : 0, ndcg, dcg);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? LTR_OK : (int)e;

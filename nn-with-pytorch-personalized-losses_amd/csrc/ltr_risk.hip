@@ -359,13 +359,18 @@ risk_matrix_kernel(const float *__restrict__ ref, const float *__restrict__ x0, 
         if (tid == 0) mat[(size_t)b * nsys + sys] = (float)m;
         if (sys == 0 && jac) {
             // g_j = d m / d x_j; mode 0: x = softmax(s): d m / d s_j = x_j (g_j - sum_k x_k g_k)
-            const bool clamped = !(nrm_v > 1e-8);       // |v| below eps: the clamp passes no gradient to the norm, d m / d v = u / den
+            // The installed torch (2.10, ATen cosine_similarity) clamps the two norms IN PLACE under no-grad: the VALUE uses
+            // max(|v|, eps), the gradient still flows through the norm as d|v| / dv = v / |v| (0 at v = 0) -- measured on a vector of
+            // norm 3e-9 (tests/test_risk_gpu.py::test_fused_risk_matrix_cosine_of_a_zero_vector):
+            //   d m / d v = u / den - m v / (max(|v|, eps) |v|)
+            const double nv_c = nrm_v > 1e-8 ? nrm_v : 1e-8;
+            const double inv_vv = nrm_v > 0.0 ? 1.0 / (nv_c * nrm_v) : 0.0;
             auto grad = [&](int j) -> double {
                 const double tj = t[j], xj = x[j];
                 if (lt == 1) return mode == 1 ? 2.0 * (xj - tj) : 2.0 * tj * (tj * xj - tj * tj);
                 if (lt == 2) {
                     const double u = mode == 2 ? tj * tj : tj, v = mode == 2 ? tj * xj : xj, w = mode == 2 ? tj : 1.0;
-                    return w * (clamped ? u / den : u / den - m * v / cnv);
+                    return w * (u / den - m * v * inv_vv);
                 }
                 return mode == 1 ? 2.0 * (sx - st) : 2.0 * (a - nt) * tj;
             };

@@ -1367,7 +1367,7 @@ __global__ void __launch_bounds__(kThreads, 2) slate_pipeline_kernel(const PipeA
 
 // The keep mask the pipeline's counter-based dropout stream produces (tests / reproducibility tooling).
 __global__ void dropout_mask_kernel(unsigned long long seed, int layer, long long n_docs, int H, unsigned thr16, uint8_t *out) {
-    const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long e = ltr_block_id() * blockDim.x + threadIdx.x;
     if (e >= n_docs * H) return;
     const long long doc = e / H;
     const int n = (int)(e - doc * H);
@@ -1608,7 +1608,7 @@ int ltr_dropout_keep_mask_p(uint64_t seed, int layer, int64_t n_docs, int H, flo
     if (n == 0) return LTR_OK;
     unsigned thr16 = p == 0.5f ? 0u : (unsigned)(p * 65536.f + 0.5f);
     if (thr16 > 65535u) thr16 = 65535u;
-    hipLaunchKernelGGL(dropout_mask_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, seed,
+    hipLaunchKernelGGL(dropout_mask_kernel, ltr_grid((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, seed,
                        layer, (long long)n_docs, H, thr16, out);
     return status();
 }
@@ -1618,7 +1618,7 @@ int ltr_dropout_keep_mask(uint64_t seed, int layer, int64_t n_docs, int H, uint8
     if (n_docs < 0 || H < 1 || H > 4096 || layer < 0 || layer > 1) return LTR_ERR_SHAPE;
     const long long n = n_docs * H;
     if (n == 0) return LTR_OK;
-    hipLaunchKernelGGL(dropout_mask_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, seed,
+    hipLaunchKernelGGL(dropout_mask_kernel, ltr_grid((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, seed,
                        layer, (long long)n_docs, H, 0u, out);
     return status();
 }

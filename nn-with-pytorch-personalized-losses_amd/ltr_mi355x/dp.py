@@ -58,6 +58,7 @@ class QueryShardedTrainer:
         # always_collective: issue the all-reduce even at world_size 1 (exercises the backend on a one-GPU box)
         self.collective = self.world_size > 1 or (always_collective and dist.is_available() and dist.is_initialized())
         self.deferred = all(hasattr(local_step, a) for a in ("flat_ext", "finish_norm"))
+        self.comm_events = None
         # every rank draws its OWN dropout stream: the keep bits are keyed on (seed, local document index), so
         # without a per-rank salt document i of every shard would share one mask (ltr_scorer.hip keep_word)
         if hasattr(self.local, "seed_salt"):
@@ -78,16 +79,25 @@ class QueryShardedTrainer:
         batch-mean loss is then pre-scaled inside the launch.  Default: deferred normalisation (see the class docstring);
         every rank must make the same choice."""
         data_dependent = getattr(self.local, "mean_kind", None) == "pairs"
+        ev = self.comm_events                   # optional (start, end) torch.cuda.Event pair around the collective (bench.py)
         if self.deferred and (global_batch is None or data_dependent):
             self.local.step(X, y, defer_norm=True)
             if self.collective:
+                if ev is not None:
+                    ev[0].record()
                 dist.all_reduce(self.local.flat_ext, op=dist.ReduceOp.SUM, group=self.group)
+                if ev is not None:
+                    ev[1].record()
             self.local.finish_norm()
         else:
             gb = int(global_batch) if global_batch else self.global_batch_of(int(X.shape[0]), X.device)
             self.local.step(X, y, world_batch=gb)
             if self.collective:
+                if ev is not None:
+                    ev[0].record()
                 dist.all_reduce(self.local.flat, op=dist.ReduceOp.SUM, group=self.group)
+                if ev is not None:
+                    ev[1].record()
         self.opt.step()
         return self.local.flat[-1]
 

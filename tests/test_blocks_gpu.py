@@ -216,11 +216,12 @@ def test_encoder_layer_with_mixed_dropout_probabilities_takes_the_composed_path(
     out.square().mean().backward()
     assert torch.isfinite(out).all() and torch.isfinite(xg.grad).all()
     assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in mixed.parameters())
-    # the fused node hands out a copy of its residual stream: an in-place edit of the output must not corrupt the backward
+    # the fused node hands out a COPY of its residual stream (kept in ctx for the backward): editing the output's storage behind
+    # autograd's back must not reach what the backward reads
     uniform.train(False)
     xg2 = x.clone().requires_grad_(True)
     o2 = uniform(xg2, mask)
     ref = torch.autograd.grad(o2.sum(), xg2, retain_graph=True)[0].clone()
-    o2.detach().zero_()
+    o2.data.zero_()
     again = torch.autograd.grad(o2.sum(), xg2)[0]
     assert torch.equal(ref, again)

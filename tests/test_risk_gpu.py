@@ -167,7 +167,8 @@ def test_fused_risk_matrix_matches_the_tensor_algebra_path(B, S, nb, lt, ideal, 
 def test_fused_risk_matrix_cosine_of_a_zero_vector(ideal, dev):
     """Cosine effectiveness (mode 1: Lambda-type column sums) when one query's model vector is all zeros: F.cosine_similarity of the
     installed torch clamps EACH norm at eps = 1e-8 (x / max(|x|, eps)), not the product -- the value is 0 and the gradient w.r.t.
-    the zero vector is ref / (|ref| eps); a near-zero vector (norm 3e-9 < eps) takes the same clamped branch."""
+    the zero vector is ref / (|ref| eps).  A near-zero vector (norm 3e-9 < eps) shows how ATen differentiates the clamp: the norms
+    are clamped in place under no-grad, so the value uses eps while the gradient still runs through d|v|/dv = v/|v|."""
     from losses.riskLosses import riskLosses as RL
     from ltr_mi355x import risk as R
     gen = torch.Generator().manual_seed(11)
