@@ -47,7 +47,8 @@ def pmc_traffic_per_launch(net, batch):
     try:
         with open(path) as f:
             rec = json.load(f)
-        e = rec.get(f"{net}_b{batch}")
+        lib_tag = "_f16x2" if "f16x2" in os.environ.get("LTR_LIB", "") else ""
+        e = rec.get(f"{net}_b{batch}{lib_tag}")
         if e:
             return int((2.0 * e["FETCH_SIZE_KiB"] + e["WRITE_SIZE_KiB"]) * 1024)
     except (OSError, ValueError, KeyError):

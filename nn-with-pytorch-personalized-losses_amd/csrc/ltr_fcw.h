@@ -34,8 +34,8 @@
 #define FCW_STAMP(k)
 #endif
 
-#ifndef FCW_KEEP_R
-#define FCW_KEEP_R 1               // pair reciprocals of the approxNDCG sweeps stay in registers between the two sweeps (64 VGPRs)
+#ifndef FCW_X_PREFETCH
+#define FCW_X_PREFETCH 2           // before the dW1 GEMM of a tile: 1 = the next tile's X rows -> registers (68 VGPRs: spills 356 B/lane), 2 = -> L2 only
 #endif
 #ifndef FCW_W1_RELOAD
 #define FCW_W1_RELOAD 1            // exact fp32: the W1 fragments are re-read from L2 per tile (9 KB per wave) instead of pinning 36 VGPRs through
@@ -131,6 +131,10 @@ __global__ void __launch_bounds__(kFcwThreads, 2) fcw_fused_kernel(const PipeArg
     for (int e = tid; e < kTileDocs * 4; e += kFcwThreads) Xs[(e >> 2) * LDX + N::F + (e & 3)] = (e & 3) ? 0.f : 1.f;
 #endif
     for (int j = tid; j < kFcwThreads + 4 * 32; j += kFcwThreads) scratch[j] = 0.f;
+    if (LOSS == 0) {
+        __syncthreads();
+        ltr_fill_inv_discount(scratch + 128, kTileDocs, tid, kFcwThreads);      // [128, 256): 1 / log2(2 + rank); [0, 64): wave partials
+    }
     f32x4 accW[XT];                                  // dW1 tiles (rows = my 16 hidden units, cols = 16 features each)
 #pragma unroll
     for (int t = 0; t < XT; ++t) accW[t] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -138,23 +142,31 @@ __global__ void __launch_bounds__(kFcwThreads, 2) fcw_fused_kernel(const PipeArg
 
     constexpr int V4_PER_ROW = N::F / 4, ROWS = kTileDocs / kFcwWaves, V4 = ROWS * V4_PER_ROW;   // this wave converts 32 rows
     constexpr int NV = (V4 + 63) / 64;
+    f32x4 xn[NV];
+    auto load_x = [&](int tile) {
+        // one buffer descriptor per wave and tile, sized to the rows that exist: the hardware bounds check returns zeros for
+        // rows past the end of the batch (no per-element compare, no 64-bit address registers)
+        static_assert(V4 % 64 == 0, "the wave's row block is a whole number of 1 KiB wave loads");
+        const long long row0 = (long long)tile * kTileDocs + ROWS * w;
+        long long rows_here = a.n_docs - row0;
+        rows_here = rows_here < 0 ? 0 : (rows_here > ROWS ? ROWS : rows_here);
+        const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.X + (rows_here ? row0 : 0) * N::F), 0,
+                                                                             (int)rows_here * N::F * 4, 0x00020000);
+#pragma unroll
+        for (int m = 0; m < NV; ++m)
+            xn[m] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xr, lane * 16 + m * 1024, 0, 2 /* nt */));
+    };
+#if FCW_X_PREFETCH == 1
+    if ((int)blockIdx.x < a.n_super) load_x(blockIdx.x);
+#endif
     for (int st = blockIdx.x; st < a.n_super; st += gridDim.x) {
         const long long doc_base = (long long)st * kTileDocs;
         FCW_STAMP(0)
-        // ---- X: this wave's 32 rows HBM -> registers (nothing in LDS is touched yet: the loads fly across the barrier)
-        f32x4 xn[NV];
-        {   // one buffer descriptor per wave and tile, sized to the rows that exist: the hardware bounds check returns zeros for
-            // rows past the end of the batch (no per-element compare, no 64-bit address registers)
-            static_assert(V4 % 64 == 0, "the wave's row block is a whole number of 1 KiB wave loads");
-            const long long row0 = doc_base + ROWS * w;
-            long long rows_here = a.n_docs - row0;
-            rows_here = rows_here < 0 ? 0 : (rows_here > ROWS ? ROWS : rows_here);
-            const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.X + (rows_here ? row0 : 0) * N::F), 0,
-                                                                                 (int)rows_here * N::F * 4, 0x00020000);
-#pragma unroll
-            for (int m = 0; m < NV; ++m)
-                xn[m] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xr, lane * 16 + m * 1024, 0, 2 /* nt */));
-        }
+        // ---- X: this wave's 32 rows are in flight (or landed) in xn: fetched ahead of time, before the previous tile's dW1 GEMM
+        //      (FCW_X_PREFETCH), so that the HBM latency hides under its MFMAs instead of opening every tile
+#if FCW_X_PREFETCH != 1
+        load_x(st);
+#endif
 #if LTR_F16X2
         float xm = 0.f;
 #pragma unroll
@@ -358,19 +370,19 @@ __global__ void __launch_bounds__(kFcwThreads, 2) fcw_fused_kernel(const PipeArg
                         const float *pp = part + so2 + j;
                         return ((pp[0] + pp[kTileDocs]) + (pp[2 * kTileDocs] + pp[3 * kTileDocs])) + b3;
                     };
-                    return approx_ndcg_fused<SS, NWS, true, FCW_KEEP_R, 8>(tid - gi * 64 * NWS, score, sc + so2, yl + so2, gn + so2, gg + so2, uu + so2,
-                                                            xt + so2, mk + so2, scratch + gi * 16, a.alpha, a.eps, a.gscale,
-                                                            [&](int i, float v) { dsc[so2 + i] = v; }, stamper);
+                    return approx_ndcg_fused<SS, NWS, true>(tid - gi * 64 * NWS, score, sc + so2, yl + so2, gn + so2, gg + so2, uu + so2,
+                                                            xt + so2, mk + so2, scratch + gi * 16, scratch + 128, a.alpha, a.eps, a.gscale,
+                                                            [&](int i, float v) { dsc[so2 + i] = v; }, stamper);      // (documents past the batch carry the pad label: gradient 0)
                 };
                 loss = run(std::integral_constant<int, ST ? ST : 128>(), std::integral_constant<int, (ST ? ST : 128) / 32>(), stamp_fn);
             } else if constexpr (LOSS == 1) {
-                loss = listnet_slate(g, yl + so, sc + so, a.apply_sigmoid != 0, a.gscale, true, [&](int i, float v) { dsc[so + i] = v; });
+                loss = listnet_slate(g, yl + so, sc + so, a.apply_sigmoid != 0, a.gscale, true, [&](int i, float v) { dsc[so + i] = slate < a.B ? v : 0.f; });
             } else {
                 LambdaLds L;
                 L.sc = sc + so; L.yl = yl + so; L.gn = gn + so; L.w1 = gg + so; L.invd = uu + so; L.delta = mk + so;
                 L.rk = reinterpret_cast<int *>(xt + so);
                 float count;
-                loss = lambda_slate<-1>(g, L, a.lp, a.gscale, true, &count, [&](int i, float v) { dsc[so + i] = v; });
+                loss = lambda_slate<-1>(g, L, a.lp, a.gscale, true, &count, [&](int i, float v) { dsc[so + i] = slate < a.B ? v : 0.f; });
                 if (g.t == 0 && slate < a.B && a.slate_count) a.slate_count[slate] = count;
             }
             if (g.t == 0 && slate < a.B) a.slate_loss[slate] = loss;
@@ -383,7 +395,8 @@ __global__ void __launch_bounds__(kFcwThreads, 2) fcw_fused_kernel(const PipeArg
         float dmx = fmaxf(fabsf(dsc[lane]), fabsf(dsc[lane + 64]));
         dmx = wave_allmax(dmx);
 #endif
-        if (w == 0) db3 += wave_allsum((lane < docs_left ? dsc[lane] : 0.f) + (lane + 64 < docs_left ? dsc[lane + 64] : 0.f));
+        // (every loss stores a ZERO score gradient for documents past the end of the batch: no per-document test below)
+        if (w == 0) db3 += wave_allsum(dsc[lane] + dsc[lane + 64]);
 #if LTR_F16X2
         exd = grow_exp(exd, dmx * slope * w3max);
         if (exd + exx != E) {
@@ -399,12 +412,30 @@ __global__ void __launch_bounds__(kFcwThreads, 2) fcw_fused_kernel(const PipeArg
             const f32x4 ds4 = *reinterpret_cast<const f32x4 *>(dsc + 16 * T + 4 * q);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const float ds = 16 * T + 4 * q + r < docs_left ? ds4[r] : 0.f;
+                const float ds = ds4[r];
                 dw3 = fmaf(ds, h1[T][r], dw3);
                 h1[T][r] = apply_act_grad<N::A1>(ds * slope * w3n, h1[T][r]);        // now dz1
             }
         }
         FCW_STAMP(8)
+#if FCW_X_PREFETCH == 1
+        if (st + (int)gridDim.x < a.n_super) load_x(st + gridDim.x);      // the next tile's rows: they land under the dW1 MFMAs below
+#elif FCW_X_PREFETCH == 2
+        // pull the NEXT tile of X into L2 while this one is in its dW1 GEMM: one dword per 128-B line per lane (544 lines); the values
+        // are only kept alive until the end of the iteration so that the loads are issued here and waited for there
+        float pf = 0.f;
+        {
+            const long long nb = (long long)(st + gridDim.x) * kTileDocs * N::F;         // first float of the next tile
+            const long long lim = a.n_docs * N::F;
+            if (st + (int)gridDim.x < a.n_super) {
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    const long long fl = nb + ((long long)tid + 256 * k) * 32;
+                    if (tid + 256 * k < (kTileDocs * N::F + 31) / 32 && fl < lim) pf += a.X[fl];
+                }
+            }
+        }
+#endif
 #if LTR_F16X2
         // ---- dW1[n][f] += sum_doc dz1[doc][n] x[doc][f]: A = two accumulator tiles of dz1 (split in registers), B = x k-major
         {
@@ -432,31 +463,41 @@ __global__ void __launch_bounds__(kFcwThreads, 2) fcw_fused_kernel(const PipeArg
         }
 #else
         // ---- dW1[n][f] += sum_doc dz1[doc][n] x[doc][f]: A = register r of the dz1 accumulator tile (k-slot q = document 4 q + r),
-        //      B = x[document 16 T + 4 q + r][16 Ti + d]; the last tile's columns past the row read the row's last float (a zero pad)
+        //      B = x[document 16 T + 4 q + r][feature of (tile Ti, column d)].  Which feature a column stands for is free (the store at
+        //      the end of the kernel undoes it): column d of tile Ti < 8 is feature 64 (Ti >> 2) + 4 d + (Ti & 3), so ONE ds_read_b128
+        //      of 4 consecutive floats feeds FOUR tiles (3 LDS instructions per step instead of 9); tile 8 keeps 128 + d, its columns
+        //      past the row read the row's last float (a zero pad).
         {
-            const float *rb = Xs + 4 * q * LDX + d;
-            const int lastc = 16 * (XT - 1) + (16 * (XT - 1) + d < LDX ? 0 : LDX - 1 - 16 * (XT - 1) - d);
-            // software pipeline over the 32 (document tile, register) steps: the nine B values of step s + 1 are in flight
-            // under the nine MFMAs (288 cycles) of step s -- left to itself the compiler reads each value right before its MFMA
-            float bx[2][XT];
-            auto load_b = [&](int step, float (&dst)[XT]) {
-                const float *pr = rb + (16 * (step >> 2) + (step & 3)) * LDX;
-#pragma unroll
-                for (int Ti = 0; Ti < XT; ++Ti) dst[Ti] = pr[Ti + 1 < XT ? 16 * Ti : lastc];
+            static_assert(XT == 9, "two groups of four feature tiles and the tail tile");
+            const float *rb = Xs + 4 * q * LDX + 4 * d;
+            const float *rt = Xs + 4 * q * LDX + (128 + d < LDX ? 128 + d : LDX - 1);
+            // software pipeline over the 32 (document tile, register) steps: the B values of step s + 1 are in flight under the nine
+            // MFMAs (288 cycles) of step s -- left to itself the compiler reads each value right before its MFMA
+            f32x4 bq[2][2];
+            float bt[2];
+            auto load_b = [&](int step, f32x4 (&dst)[2], float &dt) {
+                const int ro = (16 * (step >> 2) + (step & 3)) * LDX;
+                dst[0] = *reinterpret_cast<const f32x4 *>(rb + ro);
+                dst[1] = *reinterpret_cast<const f32x4 *>(rb + ro + 64);
+                dt = rt[ro];
             };
-            load_b(0, bx[0]);
+            load_b(0, bq[0], bt[0]);
 #pragma unroll
             for (int step = 0; step < 32; ++step) {
-                if (step + 1 < 32) load_b(step + 1, bx[(step + 1) & 1]);
+                if (step + 1 < 32) load_b(step + 1, bq[(step + 1) & 1], bt[(step + 1) & 1]);
                 __builtin_amdgcn_sched_barrier(0);
                 const float av = h1[step >> 2][step & 3];
 #pragma unroll
-                for (int Ti = 0; Ti < XT; ++Ti) accW[Ti] = mfma4(av, bx[step & 1][Ti], accW[Ti]);
+                for (int Ti = 0; Ti < 8; ++Ti) accW[Ti] = mfma4(av, bq[step & 1][Ti >> 2][Ti & 3], accW[Ti]);
+                accW[8] = mfma4(av, bt[step & 1], accW[8]);
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
 #endif
         FCW_STAMP(9)
+#if FCW_X_PREFETCH == 2
+        asm volatile("" ::"v"(pf));   // keep the prefetch loads alive (and waited for) until here
+#endif
     }
     // ---- per-workgroup partial gradients -> workspace (the layout reduce_grads_kernel<N> sums)
     float *out = a.partials + (size_t)blockIdx.x * N::PART;
@@ -466,9 +507,15 @@ __global__ void __launch_bounds__(kFcwThreads, 2) fcw_fused_kernel(const PipeArg
     const float us = 1.f;
 #endif
 #pragma unroll
-    for (int Ti = 0; Ti < XT; ++Ti)
+    for (int Ti = 0; Ti < XT; ++Ti) {
+#if LTR_F16X2
+        const int col = 16 * Ti + d;
+#else
+        const int col = Ti < 8 ? 64 * (Ti >> 2) + 4 * d + (Ti & 3) : 128 + d;       // the feature column d of tile Ti stands for (dW1 above)
+#endif
 #pragma unroll
-        for (int r = 0; r < 4; ++r) out[N::P_W1 + (16 * w + 4 * q + r) * (XT * 16) + 16 * Ti + d] = accW[Ti][r] * us;
+        for (int r = 0; r < 4; ++r) out[N::P_W1 + (16 * w + 4 * q + r) * (XT * 16) + col] = accW[Ti][r] * us;
+    }
     dw3 += __shfl_xor(dw3, 16, 64);
     dw3 += __shfl_xor(dw3, 32, 64);
     if (lane < 16) out[N::P_W3 + 16 * w + lane] = dw3;

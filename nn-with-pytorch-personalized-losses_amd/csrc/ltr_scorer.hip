@@ -743,6 +743,18 @@ __device__ __forceinline__ void dma_x_rows(const PipeArgs &a, float *Xs, long lo
 }
 
 #include "ltr_fcw.h"
+// The weights-stationary kernel for the live DoubleLayerNet (ltr_wst.h): correct (the whole fused test matrix
+// passes with it) but SLOWER than the generic pipeline on this chip -- 0.567 of the fp32 MFMA peak (8 waves) / 0.529 (4 waves, 512
+// registers) against 0.612 -- so it is an opt-in build (-DLTR_WST=1, tools/build_variant.sh), not part of the shipped libraries.
+#ifndef LTR_WST
+#define LTR_WST 0
+#endif
+#if LTR_WST
+#ifndef WST_WAVES
+#define WST_WAVES 8
+#endif
+#include "ltr_wst.h"
+#endif
 
 // ST (MODE_FUSED with approxNDCG only): 128 = the slate length is the compile-time constant 128 (the kernel then carries ONE copy
 // of the loss: three copies cost the 136-wide kernel 180 B/lane of scratch); 0 = a.S at run time.
@@ -782,7 +794,11 @@ __global__ void __launch_bounds__(kThreads, 2) slate_pipeline_kernel(const PipeA
 #endif
     for (int j = tid; j < N::NT2 * 16 + 16; j += kThreads) w3s[j] = a.packed[N::W3_OFF + j];
     for (int j = tid; j < kWaves * N::NT2 * 16; j += kThreads) dw3[j] = 0.f;
-    for (int j = tid; j < kThreads + 4 * 32; j += kThreads) scratch[j] = 0.f;   // incl. the label bins of approx_ndcg_slate
+    for (int j = tid; j < kThreads + 4 * 32; j += kThreads) scratch[j] = 0.f;   // slate-group scratch (ListNet / LambdaLoss groups; approxNDCG: [0, 128) wave partials)
+    if (MODE == MODE_FUSED && LOSS == 0) {
+        __syncthreads();
+        ltr_fill_inv_discount(scratch + 256, kTileDocs, tid, kThreads);          // [256, 384): 1 / log2(2 + rank)
+    }
     float db3 = 0.f;
     f32x4 accW1[N::TW1], accW2[N::TW2];
     if (MODE != MODE_FWD) {
@@ -1076,9 +1092,9 @@ __global__ void __launch_bounds__(kThreads, 2) slate_pipeline_kernel(const PipeA
                     constexpr int SS = decltype(s_tag)::value, NWS = decltype(nw_tag)::value;
                     const int gi = tl / (64 * NWS), so2 = gi * SS;
                     const float *scp = sc + so2;
-                    return approx_ndcg_fused<SS, NWS, false, false, (N::H1 <= 64 ? 4 : LTR_LOSS_UNR)>(tl - gi * 64 * NWS, [&](int j) { return scp[j]; }, sc + so2, yl + so2, gn + so2,
-                                                             gg + so2, uu + so2, xt + so2, mk + so2, scratch + gi * 32, a.alpha, a.eps,
-                                                             a.gscale, [&](int i, float v) { dsc[so2 + i] = v; }, stamper);
+                    return approx_ndcg_fused_shared<SS, NWS, false>(tl - gi * 64 * NWS, [&](int j) { return scp[j]; }, sc + so2, yl + so2, gn + so2,
+                                                                    gg + so2, uu + so2, xt + so2, mk + so2, scratch + gi * 32, scratch + 256, a.alpha, a.eps,
+                                                                    a.gscale, [&](int i, float v) { dsc[so2 + i] = v; }, stamper);
                 };
                 if constexpr (ST == 128) loss = run(std::integral_constant<int, 128>(), std::integral_constant<int, 8>(), stamp_fn);
                 else if (a.S == 128) loss = run(std::integral_constant<int, 128>(), std::integral_constant<int, 8>(), stamp_fn);
@@ -1562,6 +1578,14 @@ int pipeline_dispatch(int mode, const PipeArgs &a, int grid, hipStream_t stream)
                     case 1: return launch_fcw<N, 1>(a, grid, stream);
                     default: return launch_fcw<N, 2>(a, grid, stream);
                 }
+#if LTR_WST
+            } else if constexpr (std::is_same<N, DoubleNet>::value) {
+                switch (a.loss_kind) {       // the live DoubleLayerNet: weights-stationary kernel, one workgroup per CU
+                    case 0: return launch_wst<N, 0>(a, grid, stream);
+                    case 1: return launch_wst<N, 1>(a, grid, stream);
+                    default: return launch_wst<N, 2>(a, grid, stream);
+                }
+#endif
             } else {
                 switch (a.loss_kind) {
                     case 0:

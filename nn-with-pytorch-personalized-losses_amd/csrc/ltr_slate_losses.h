@@ -345,6 +345,11 @@ __device__ __forceinline__ float approx_ndcg_slate(const SlateGroup &g, float *s
     return -total;
 }
 
+// invd[r] = 1 / log2(2 + r), r < n: the rank discounts of the ideal DCG (approxNDCG.py:41-43), same expression as the per-row epilogue
+__device__ __forceinline__ void ltr_fill_inv_discount(float *invd, int n, int tid, int nthreads) {
+    for (int r = tid; r < n; r += nthreads) invd[r] = ltr_rcp(__log2f(2.f + (float)r));
+}
+
 // ------------------------------------------------------------------------------------------------
 // approxNDCG for the FUSED kernels (ltr_fcw.h, slate_pipeline_kernel): same maths and the same three paths as
 // approx_ndcg_slate above (losses/approxNDCG.py:7-53), restructured so that a slate costs ONE workgroup barrier instead of four.
@@ -363,13 +368,13 @@ __device__ __forceinline__ float approx_ndcg_slate(const SlateGroup &g, float *s
 //   * one barrier publishes the per-document gradient weights gg (and the per-wave loss / ideal-DCG partials) between the two
 //     sweeps; the caller's barrier behind the call publishes the score gradients.
 // `score(j)` returns the score of document j (the fused kernels sum their per-wave partials here: no separate exchange pass);
-// every wave calls it for all S documents.  sc / uu / um / mk / gg: LDS [S]; red: LDS [2 NW], private to the slate.
+// every wave calls it for all S documents.  sc / uu / um / mk / gg: LDS [S]; red: LDS [2 NW], private to the slate; invd: LDS [>= S],
+// invd[r] = 1 / log2(2 + r) (ltr_fill_inv_discount once per kernel: as registers those per-lane constants were hoisted and spilled).
 // t = the thread's index inside the slate's 64 NW threads.  All threads of the BLOCK must call (one __syncthreads inside).
-// UNR (!KEEP_R only): eight-column trips unrolled in the sweeps; 1 in the 136-wide kernels, which sit at their register limit.
-template <int S, int NW, bool WRITE_SC, bool KEEP_R, int UNR, class Score, class Store, class Stamp = NoStamp>
+template <int S, int NW, bool WRITE_SC, class Score, class Store, class Stamp = NoStamp>
 __device__ __forceinline__ float approx_ndcg_fused(int t, Score score, float *sc, const float *yl, const float *gn, float *gg,
-                                                   float *uu, float *um, float *mk, float *red, float alpha, float eps,
-                                                   float gscale, Store store, Stamp stamp = Stamp()) {
+                                                   float *uu, float *um, float *mk, float *red, const float *invd, float alpha,
+                                                   float eps, float gscale, Store store, Stamp stamp = Stamp()) {
     static_assert(S == 32 || S == 64 || S == 128, "fused slates are 32, 64 or 128 documents");
     constexpr int CG = 64 * NW / S;                 // lanes per row
     static_assert(CG == 2 || CG == 4, "two or four lanes per document row");
@@ -423,7 +428,7 @@ __device__ __forceinline__ float approx_ndcg_fused(int t, Score score, float *sc
     const float ui = uu[i];
     float total = 0.f;
     // state handed from the first half of a path (up to the barrier) to its second half
-    float rr[KEEP_R ? 4 * QPL : 1];          // KEEP_R: pair reciprocals of the no-clamp path, sweep 1 -> sweep 2
+    float rr[4 * QPL];                       // pair reciprocals of the no-clamp path, sweep 1 -> sweep 2
     float idcg_u = 0.f, gout = 0.f, loss_acc = 0.f, idcg_acc = 0.f;
 
     // ================= no-clamp path: integer grades, |alpha (s_k - s_0)| <= 8 =================
@@ -450,44 +455,27 @@ __device__ __forceinline__ float approx_ndcg_fused(int t, Score score, float *sc
             }
             float acc = 0.f;
 #pragma unroll
-            for (int sl = 0; sl < SLOTS; ++sl) acc = fmaf(gr[sl], ltr_rcp(__log2f(2.f + (float)(lane + 64 * sl))), acc);
+            for (int sl = 0; sl < SLOTS; ++sl) acc = fmaf(gr[sl], invd[(lane + 64 * sl) & (S - 1)], acc);      // 1 / log2(2 + rank): LDS table
             idcg_u = wave_allsum(acc);
         }
         stamp(10);
         stamp(11);
         // ---- sweep 1: pos_i - 1 = sum_j um_j / (u_i + u_j) - 1/2 [i real]
-        // KEEP_R: the pair reciprocals r_ij = 1 / (u_i + u_j) of this lane's 4 QPL columns STAY IN REGISTERS from sweep 1 to sweep 2
+        // The pair reciprocals r_ij = 1 / (u_i + u_j) of this lane's 4 QPL columns STAY IN REGISTERS from sweep 1 to sweep 2
         // (64 VGPRs at two lanes per row, 32 at four): sweep 1 is add + v_rcp_f32 + fma per pair, sweep 2 one multiply and two fma
         // -- 7 issue slots per ordered pair against 11.25 for the two four-pairs-per-reciprocal sweeps (whose batching saves
         // nothing where a lone wave issues v_rcp_f32 in two plain slots, profiles/r04_simd_coissue_microbench.jsonl).
-        // !KEEP_R (kernels without the registers to spare): four pair terms share ONE v_rcp_f32, as in approx_ndcg_slate.
         float acc0 = 0.f, acc1 = 0.f;
-        if constexpr (KEEP_R) {
 #pragma unroll
-            for (int m = 0; m < QPL; ++m) {
-                const lds_f4 u = *reinterpret_cast<const lds_f4 *>(ub + 4 * CG * m);
-                const lds_f4 n = *reinterpret_cast<const lds_f4 *>(nb + 4 * CG * m);
+        for (int m = 0; m < QPL; ++m) {
+            const lds_f4 u = *reinterpret_cast<const lds_f4 *>(ub + 4 * CG * m);
+            const lds_f4 n = *reinterpret_cast<const lds_f4 *>(nb + 4 * CG * m);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) rr[4 * m + e] = ltr_rcp(ui + u[e]);
-                acc0 = fmaf(n[0], rr[4 * m + 0], acc0);
-                acc1 = fmaf(n[1], rr[4 * m + 1], acc1);
-                acc0 = fmaf(n[2], rr[4 * m + 2], acc0);
-                acc1 = fmaf(n[3], rr[4 * m + 3], acc1);
-            }
-        } else {
-            auto quad = [&](int m, float acc) {
-                const lds_f4 u = *reinterpret_cast<const lds_f4 *>(ub + 4 * CG * m);
-                const lds_f4 n = *reinterpret_cast<const lds_f4 *>(nb + 4 * CG * m);
-                const float d0 = ui + u[0], d1 = ui + u[1], d2 = ui + u[2], d3 = ui + u[3];
-                const float D01 = d0 * d1, D23 = d2 * d3;
-                const float N01 = fmaf(n[0], d1, n[1] * d0), N23 = fmaf(n[2], d3, n[3] * d2);
-                return fmaf(fmaf(N01, D23, N23 * D01), ltr_rcp(D01 * D23), acc);
-            };
-#pragma unroll UNR
-            for (int m = 0; m < QPL; m += 2) {
-                acc0 = quad(m, acc0);
-                acc1 = quad(m + 1, acc1);
-            }
+            for (int e = 0; e < 4; ++e) rr[4 * m + e] = ltr_rcp(ui + u[e]);
+            acc0 = fmaf(n[0], rr[4 * m + 0], acc0);
+            acc1 = fmaf(n[1], rr[4 * m + 1], acc1);
+            acc0 = fmaf(n[2], rr[4 * m + 2], acc0);
+            acc1 = fmaf(n[3], rr[4 * m + 3], acc1);
         }
         float p = acc0 + acc1;
         if (mine) p -= 0.5f;                                     // the j == i term: u_i / (2 u_i)
@@ -501,8 +489,8 @@ __device__ __forceinline__ float approx_ndcg_fused(int t, Score score, float *sc
             loss_acc = gl;
             gout = gl * iL * ltr_rcp((1.f + pos) * LTR_LN2);     // d(-sum gain/L)/d pos_i, not yet / maxDCG
         }
-        // KEEP_R: column j of sweep 2 needs only um_j g_j (um_i = u_i for a real document); otherwise g_j itself
-        if (cg == 0) gg[i] = KEEP_R ? gout * ui : gout;          // 0 for padded documents
+        // column j of sweep 2 needs only um_j g_j (um_i = u_i for a real document)
+        if (cg == 0) gg[i] = gout * ui;                          // 0 for padded documents
         stamp(12);
         loss_acc = wave_allsum(loss_acc);
     };
@@ -511,45 +499,22 @@ __device__ __forceinline__ float approx_ndcg_fused(int t, Score score, float *sc
         total = loss_sum * inv_idcg;
         // ---- sweep 2: d loss / d s_k = alpha u_k sum_j um_j (g_j - g_k) / (u_k + u_j)^2       (k = i)
         const float gk = LTR_DPP(gout, CG == 2 ? 0xA0 : 0x00);   // g_k from the row's first lane (quad_perm broadcast)
-        float a;
-        if constexpr (KEEP_R) {
-            // a_k = u_k (sum_j um_j g_j r_kj^2 - g_k sum_j um_j r_kj^2); the j == k terms of the two sums cancel
-            float A0 = 0.f, A1 = 0.f, T0 = 0.f, T1 = 0.f;
+        // a_k = u_k (sum_j um_j g_j r_kj^2 - g_k sum_j um_j r_kj^2); the j == k terms of the two sums cancel
+        float A0 = 0.f, A1 = 0.f, T0 = 0.f, T1 = 0.f;
 #pragma unroll
-            for (int m = 0; m < QPL; ++m) {
-                const lds_f4 mg = *reinterpret_cast<const lds_f4 *>(gb + 4 * CG * m);
-                const lds_f4 n = *reinterpret_cast<const lds_f4 *>(nb + 4 * CG * m);
+        for (int m = 0; m < QPL; ++m) {
+            const lds_f4 mg = *reinterpret_cast<const lds_f4 *>(gb + 4 * CG * m);
+            const lds_f4 n = *reinterpret_cast<const lds_f4 *>(nb + 4 * CG * m);
 #pragma unroll
-                for (int e = 0; e < 4; e += 2) {
-                    const float q0 = rr[4 * m + e] * rr[4 * m + e], q1 = rr[4 * m + e + 1] * rr[4 * m + e + 1];
-                    A0 = fmaf(mg[e], q0, A0);
-                    T0 = fmaf(n[e], q0, T0);
-                    A1 = fmaf(mg[e + 1], q1, A1);
-                    T1 = fmaf(n[e + 1], q1, T1);
-                }
+            for (int e = 0; e < 4; e += 2) {
+                const float q0 = rr[4 * m + e] * rr[4 * m + e], q1 = rr[4 * m + e + 1] * rr[4 * m + e + 1];
+                A0 = fmaf(mg[e], q0, A0);
+                T0 = fmaf(n[e], q0, T0);
+                A1 = fmaf(mg[e + 1], q1, A1);
+                T1 = fmaf(n[e + 1], q1, T1);
             }
-            a = ui * ((A0 + A1) - gk * (T0 + T1));
-        } else {
-            auto quad = [&](int m, float acc) {
-                const lds_f4 u = *reinterpret_cast<const lds_f4 *>(ub + 4 * CG * m);
-                const lds_f4 n = *reinterpret_cast<const lds_f4 *>(nb + 4 * CG * m);
-                const lds_f4 gj = *reinterpret_cast<const lds_f4 *>(gb + 4 * CG * m);
-                float q0 = ui + u[0], q1 = ui + u[1], q2 = ui + u[2], q3 = ui + u[3];
-                q0 *= q0, q1 *= q1, q2 *= q2, q3 *= q3;
-                const float t0 = n[0] * (gj[0] - gk), t1 = n[1] * (gj[1] - gk);                     // exactly 0 at j == k
-                const float t2 = n[2] * (gj[2] - gk), t3 = n[3] * (gj[3] - gk);
-                const float Q01 = q0 * q1, Q23 = q2 * q3;
-                const float N01 = fmaf(t0, q1, t1 * q0), N23 = fmaf(t2, q3, t3 * q2);
-                return fmaf(fmaf(N01, Q23, N23 * Q01), ltr_rcp(Q01 * Q23), acc);
-            };
-            float b0 = 0.f, b1 = 0.f;
-#pragma unroll UNR
-            for (int m = 0; m < QPL; m += 2) {
-                b0 = quad(m, b0);
-                b1 = quad(m + 1, b1);
-            }
-            a = ui * (b0 + b1);
         }
+        float a = ui * ((A0 + A1) - gk * (T0 + T1));
         a += LTR_DPP(a, LTR_DPP_XOR1);
         if (CG == 4) a += LTR_DPP(a, LTR_DPP_XOR2);
         if (cg == 0) store(i, vi ? alpha * gscale * inv_idcg * a : 0.f);
@@ -674,29 +639,271 @@ __device__ __forceinline__ float approx_ndcg_fused(int t, Score score, float *sc
         }
         stamp(13);
     };
-    // The path branches are WAVE-uniform (ballots).  SPLIT composition (KEEP_R kernels): each path runs start to end inside its own
-    // branch, with its own __syncthreads() -- waves of different slates of one workgroup may take different branches, every wave
-    // still arrives at exactly one s_barrier per call; keeping the paths apart is what lets the common path hold its pair
-    // reciprocals in registers across the barrier without a three-way merge of everything else that is live.  Otherwise: one
-    // barrier site between the halves (the 136-wide kernels allocate registers better that way, profiles/r04_variant_ab.json).
+    // The path branch is WAVE-uniform (ballots); each path runs start to end inside its own branch, with its own __syncthreads():
+    // waves of different slates of one workgroup may take different branches -- every wave still arrives at exactly one s_barrier
+    // per call.  Keeping the paths apart is what lets the common path hold its pair reciprocals in registers across the barrier
+    // without a three-way merge of everything else that is live (the shared-sweep form spilled 384 B/lane in the fcw kernel).
     float ls, is;
-    if constexpr (KEEP_R) {
-        if (ultra) {
-            ultra_first();
-            exchange(ls, is);
-            ultra_second(ls);
+    if (ultra) {
+        ultra_first();
+        exchange(ls, is);
+        ultra_second(ls);
+    } else {
+        general_first();
+        exchange(ls, is);
+        general_second(ls, is);
+    }
+    return -total;
+}
+
+// ------------------------------------------------------------------------------------------------
+// The same loss with ONE barrier site and shared sweeps (the path decides inside each half): the form the 136-wide pipeline
+// kernels allocate registers best with (profiles/r04_variant_ab.json: 0.614 of the fp32 MFMA peak against 0.594 for the
+// same halves composed from lambdas, which is the same arithmetic).  Four pair terms share one v_rcp_f32.
+template <int S, int NW, bool WRITE_SC, class Score, class Store, class Stamp = NoStamp>
+__device__ __forceinline__ float approx_ndcg_fused_shared(int t, Score score, float *sc, const float *yl, const float *gn, float *gg,
+                                                          float *uu, float *um, float *mk, float *red, const float *invd, float alpha,
+                                                          float eps, float gscale, Store store, Stamp stamp = Stamp()) {
+    static_assert(S == 32 || S == 64 || S == 128, "fused slates are 32, 64 or 128 documents");
+    constexpr int CG = 64 * NW / S;                 // lanes per row
+    static_assert(CG == 2 || CG == 4, "two or four lanes per document row");
+    constexpr int RPW = 64 / CG;                    // rows per wave
+    constexpr int QPL = S / 4 / CG;                 // column quads per lane
+    static_assert(QPL % 2 == 0, "two accumulator chains");
+    constexpr int SLOTS = (S + 63) / 64;            // documents per lane in the prologue
+    const int lane = t & 63;
+    const int wig = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int cg = lane & (CG - 1);
+    const int i = wig * RPW + lane / CG;            // this lane's row
+    const bool ultra_ok = eps <= 1e-7f;
+
+    // ---- prologue (wave-private)
+    float sv[SLOTS], yc[SLOTS];
+    bool real[SLOTS];
+    bool bad = false, noultra = false;
+    float ymax = 0.f;
+#pragma unroll
+    for (int sl = 0; sl < SLOTS; ++sl) {
+        const int j = lane + 64 * sl;
+        const bool act = (S % 64 == 0) || j < S;
+        sv[sl] = act ? score(act ? j : 0) : 0.f;
+        real[sl] = act && gn[act ? j : 0] >= 0.f;
+        yc[sl] = act ? fmaxf(yl[act ? j : 0], 0.f) : 0.f;
+    }
+    const float sref = alpha * lane_bcast(sv[0], 0);
+#pragma unroll
+    for (int sl = 0; sl < SLOTS; ++sl) {
+        const int j = lane + 64 * sl;
+        const bool act = (S % 64 == 0) || j < S;
+        const float x = real[sl] ? alpha * sv[sl] - sref : 0.f;
+        bad = bad || !(fabsf(x) <= 69.f);            // NaN scores take the slow path too
+        noultra = noultra || !(fabsf(x) <= 8.f);
+        const float u = real[sl] ? expf(x) : 1.f;
+        const bool isint = yc[sl] <= 15.f && yc[sl] == floorf(yc[sl]);
+        noultra = noultra || (real[sl] && !isint);
+        ymax = fmaxf(ymax, (real[sl] && isint) ? yc[sl] : 0.f);
+        if (act) {
+            uu[j] = u;
+            um[j] = real[sl] ? u : 0.f;
+            mk[j] = real[sl] ? 1.f : 0.f;
+            if (WRITE_SC) sc[j] = sv[sl];
+        }
+    }
+    const bool fast = __ballot(bad) == 0ull;
+    const bool ultra = ultra_ok && fast && __ballot(noultra) == 0ull;
+    float idcg_own = 0.f;
+    if (ultra) {
+        // ideal DCG from the label histogram (see approx_ndcg_fused): counts by ballot, wave-uniform, no LDS
+        const int ytop = __builtin_amdgcn_readfirstlane((int)wave_allmax(ymax));
+        float gr[SLOTS];
+#pragma unroll
+        for (int sl = 0; sl < SLOTS; ++sl) gr[sl] = 0.f;
+        int cum = 0;
+        for (int v = ytop; v >= 1; --v) {
+            int c = 0;
+#pragma unroll
+            for (int sl = 0; sl < SLOTS; ++sl) c += __popcll(__ballot(real[sl] && yc[sl] == (float)v));
+            const float gain = (float)((1 << v) - 1);
+#pragma unroll
+            for (int sl = 0; sl < SLOTS; ++sl) {
+                const int r = lane + 64 * sl;
+                gr[sl] = (r >= cum && r < cum + c) ? gain : gr[sl];
+            }
+            cum += c;
+        }
+        float acc = 0.f;
+#pragma unroll
+        for (int sl = 0; sl < SLOTS; ++sl) acc = fmaf(gr[sl], invd[(lane + 64 * sl) & (S - 1)], acc);      // 1 / log2(2 + rank): LDS table
+        idcg_own = wave_allsum(acc);
+    }
+    stamp(10);
+    stamp(11);
+
+    // ---- sweep 1: soft rank of row i (and, off the no-clamp path, its label rank by counting)
+    const float *ub = uu + 4 * cg, *nb = um + 4 * cg, *mb = mk + 4 * cg, *gb = gg + 4 * cg;
+    const bool mine = ((i >> 2) & (CG - 1)) == cg;          // the j == i column is one of this lane's
+    const bool vi = gn[i] >= 0.f;
+    const float ui = uu[i];
+    float p = 0.f, cnt = 0.f;
+    if (ultra) {
+        auto quad = [&](int m, float acc) {
+            const lds_f4 u = *reinterpret_cast<const lds_f4 *>(ub + 4 * CG * m);
+            const lds_f4 n = *reinterpret_cast<const lds_f4 *>(nb + 4 * CG * m);
+            const float d0 = ui + u[0], d1 = ui + u[1], d2 = ui + u[2], d3 = ui + u[3];
+            const float D01 = d0 * d1, D23 = d2 * d3;
+            const float N01 = fmaf(n[0], d1, n[1] * d0), N23 = fmaf(n[2], d3, n[3] * d2);
+            return fmaf(fmaf(N01, D23, N23 * D01), ltr_rcp(D01 * D23), acc);
+        };
+        float acc0 = 0.f, acc1 = 0.f;
+#pragma unroll
+        for (int m = 0; m < QPL; m += 2) {
+            acc0 = quad(m, acc0);
+            acc1 = quad(m + 1, acc1);
+        }
+        p = acc0 + acc1;
+        if (mine) p -= 0.5f;                                     // the j == i term: u_i / (2 u_i)
+    } else {
+        const float yi = yl[i];
+        {
+            float c0 = 0.f, c1 = 0.f, c2 = 0.f, c3 = 0.f;
+            const float *yb = yl + 4 * cg;
+#pragma unroll 2
+            for (int m = 0; m < QPL; ++m) {
+                const int j = 4 * (cg + CG * m);
+                const lds_f4 y = *reinterpret_cast<const lds_f4 *>(yb + 4 * CG * m);
+                c0 += ((y[0] > yi) || (y[0] == yi && j + 0 < i)) ? 1.f : 0.f;
+                c1 += ((y[1] > yi) || (y[1] == yi && j + 1 < i)) ? 1.f : 0.f;
+                c2 += ((y[2] > yi) || (y[2] == yi && j + 2 < i)) ? 1.f : 0.f;
+                c3 += ((y[3] > yi) || (y[3] == yi && j + 3 < i)) ? 1.f : 0.f;
+            }
+            cnt = (c0 + c1) + (c2 + c3);
+        }
+        if (fast) {
+            float p0 = 0.f, p1 = 0.f, p2 = 0.f, p3 = 0.f;
+#pragma unroll 2
+            for (int m = 0; m < QPL; ++m) {
+                const lds_f4 u = *reinterpret_cast<const lds_f4 *>(ub + 4 * CG * m);
+                const lds_f4 mm = *reinterpret_cast<const lds_f4 *>(mb + 4 * CG * m);
+                p0 = fmaf(mm[0], fmaxf(u[0] * ltr_rcp(ui + u[0]), eps), p0);
+                p1 = fmaf(mm[1], fmaxf(u[1] * ltr_rcp(ui + u[1]), eps), p1);
+                p2 = fmaf(mm[2], fmaxf(u[2] * ltr_rcp(ui + u[2]), eps), p2);
+                p3 = fmaf(mm[3], fmaxf(u[3] * ltr_rcp(ui + u[3]), eps), p3);
+            }
+            p = (p0 + p1) + (p2 + p3);
+            if (mine) p -= fmaxf(ui * ltr_rcp(ui + ui), eps);    // the j == i term
         } else {
-            general_first();
-            exchange(ls, is);
-            general_second(ls, is);
+            const float si = sc[i];
+            for (int m = 0; m < QPL; ++m)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int j = 4 * (cg + CG * m) + e;
+                    const float ex = __expf(alpha * (si - sc[j]));
+                    const float c = fmaxf(ltr_rcp(1.f + ex), eps);
+                    p += (j != i && mk[j] != 0.f) ? c : 0.f;
+                }
+        }
+    }
+    // the CG partials of a row sit in adjacent lanes
+    p += LTR_DPP(p, LTR_DPP_XOR1);
+    if (CG == 4) p += LTR_DPP(p, LTR_DPP_XOR2);
+    float idcg_acc = 0.f, loss_acc = 0.f, gout = 0.f;
+    const float pos = 1.f + p;
+    if (ultra) {
+        if (vi && cg == 0) {
+            const float iL = ltr_rcp(__log2f(1.f + pos));
+            const float gl = gn[i] * iL;
+            loss_acc = gl;
+            gout = gl * iL * ltr_rcp((1.f + pos) * LTR_LN2);     // d(-sum gain/L)/d pos_i, not yet / maxDCG
         }
     } else {
-        if (ultra) ultra_first();
-        else general_first();
-        exchange(ls, is);
-        if (ultra) ultra_second(ls);
-        else general_second(ls, is);
+        cnt += LTR_DPP(cnt, LTR_DPP_XOR1);
+        if (CG == 4) cnt += LTR_DPP(cnt, LTR_DPP_XOR2);
+        if (vi && cg == 0) {
+            const float gain = gn[i];
+            const float L = log2f(1.f + pos);
+            if (gain > 0.f) idcg_acc = gain / log2f(2.f + cnt);
+            loss_acc = gain / L;
+            gout = gain / (L * L * (1.f + pos) * LTR_LN2);
+        }
     }
+    if (cg == 0) gg[i] = gout;                                   // 0 for padded documents
+    stamp(12);
+    loss_acc = wave_allsum(loss_acc);
+    if (!ultra) idcg_acc = wave_allsum(idcg_acc);
+    if (lane == 0) {
+        red[wig] = loss_acc;
+        red[NW + wig] = idcg_acc;
+    }
+    __syncthreads();                                             // gg and the wave partials are out
+    float loss_sum = 0.f, idcg_sum = 0.f;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) {
+        loss_sum += red[w];
+        idcg_sum += red[NW + w];
+    }
+    stamp(13);
+    const float inv_idcg = 1.f / fmaxf(ultra ? idcg_own : idcg_sum, eps);   // maxDCG clamp (:43)
+    const float total = loss_sum * inv_idcg;
+
+    // ---- sweep 2: d loss / d s_k = alpha * sum_j t_kj (g_j [c_jk >= eps] - g_k [c_kj >= eps]),  t = c_kj c_jk   (k = i)
+    const float kscale = alpha * gscale * inv_idcg;
+    const float gk = gg[i];
+    float a = 0.f;
+    if (ultra) {
+        auto quad = [&](int m, float acc) {
+            const lds_f4 u = *reinterpret_cast<const lds_f4 *>(ub + 4 * CG * m);
+            const lds_f4 n = *reinterpret_cast<const lds_f4 *>(nb + 4 * CG * m);
+            const lds_f4 gj = *reinterpret_cast<const lds_f4 *>(gb + 4 * CG * m);
+            float q0 = ui + u[0], q1 = ui + u[1], q2 = ui + u[2], q3 = ui + u[3];
+            q0 *= q0, q1 *= q1, q2 *= q2, q3 *= q3;
+            const float t0 = n[0] * (gj[0] - gk), t1 = n[1] * (gj[1] - gk);                     // exactly 0 at j == k
+            const float t2 = n[2] * (gj[2] - gk), t3 = n[3] * (gj[3] - gk);
+            const float Q01 = q0 * q1, Q23 = q2 * q3;
+            const float N01 = fmaf(t0, q1, t1 * q0), N23 = fmaf(t2, q3, t3 * q2);
+            return fmaf(fmaf(N01, Q23, N23 * Q01), ltr_rcp(Q01 * Q23), acc);
+        };
+        float acc0 = 0.f, acc1 = 0.f;
+#pragma unroll
+        for (int m = 0; m < QPL; m += 2) {
+            acc0 = quad(m, acc0);
+            acc1 = quad(m + 1, acc1);
+        }
+        a = ui * (acc0 + acc1);
+    } else if (fast) {
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+#pragma unroll 2
+        for (int m = 0; m < QPL; ++m) {
+            const lds_f4 u = *reinterpret_cast<const lds_f4 *>(ub + 4 * CG * m);
+            const lds_f4 mm = *reinterpret_cast<const lds_f4 *>(mb + 4 * CG * m);
+            const lds_f4 gj = *reinterpret_cast<const lds_f4 *>(gb + 4 * CG * m);
+#define LTR_PAIR(e, acc)                                                            \
+    {                                                                               \
+        const float r = ltr_rcp(ui + u[e]);                                         \
+        const float ckj = u[e] * r, cjk = ui * r;                                   \
+        const float term = (cjk >= eps ? gj[e] : 0.f) - (ckj >= eps ? gk : 0.f);    \
+        acc = fmaf(mm[e] * (ckj * cjk), term, acc);                                 \
+    }
+            LTR_PAIR(0, a0) LTR_PAIR(1, a1) LTR_PAIR(2, a2) LTR_PAIR(3, a3)
+#undef LTR_PAIR
+        }
+        a = (a0 + a1) + (a2 + a3);              // j == k contributes exactly 0 (term = g_k - g_k)
+    } else {
+        const float sk = sc[i];
+        for (int m = 0; m < QPL; ++m)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int j = 4 * (cg + CG * m) + e;
+                const float ex = __expf(alpha * (sk - sc[j]));
+                const float ckj = ltr_rcp(1.f + ex);                  // sigmoid(-alpha (s_k - s_j))
+                const float cjk = (ex < 1e30f) ? ex * ckj : 1.f;      // sigmoid(-alpha (s_j - s_k))
+                const float term = (cjk >= eps ? gg[j] : 0.f) - (ckj >= eps ? gk : 0.f);
+                a += (j != i && mk[j] != 0.f) ? ckj * cjk * term : 0.f;
+            }
+    }
+    a += LTR_DPP(a, LTR_DPP_XOR1);
+    if (CG == 4) a += LTR_DPP(a, LTR_DPP_XOR2);
+    if (cg == 0) store(i, vi ? kscale * a : 0.f);
+    stamp(14);
     return -total;
 }
 

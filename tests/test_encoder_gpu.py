@@ -394,6 +394,38 @@ def _build(case, g):
     return net.to(DEV), sd
 
 
+_NOISE_SCALED = {}
+
+
+def _max_norm_factor_4():
+    """Named single-entry outliers (tests/golden/encoder_noise_scaled.json): max-norm gated at 4 x the self-test's deviation."""
+    import json
+    import os
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "encoder_noise_scaled.json")
+    if not os.path.exists(path):
+        return set()
+    with open(path) as f:
+        return set(json.load(f).get("max_norm_factor_4", []))
+
+
+def _noise_scaled(what, tensor, n_max, n_l2, e_max, e_l2):
+    """A tensor gated at the noise-scaled bar: recorded (gpurun_out/encoder_noise_scaled.json) and checked against the committed
+    list -- a NEW tensor drifting above the fixed bar fails here instead of quietly widening its own bar."""
+    import json
+    import os
+    key = f"{what}::{tensor}"
+    _NOISE_SCALED[key] = {"self_noise_max": n_max, "self_noise_l2": n_l2, "kernel_max": e_max, "kernel_l2": e_l2}
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    os.makedirs(os.path.join(root, "gpurun_out"), exist_ok=True)
+    with open(os.path.join(root, "gpurun_out", "encoder_noise_scaled.json"), "w") as f:
+        json.dump(_NOISE_SCALED, f, indent=1)
+    allowed = os.path.join(root, "tests", "golden", "encoder_noise_scaled.json")
+    if os.path.exists(allowed):
+        with open(allowed) as f:
+            names = set(json.load(f)["tensors"])
+        assert key in names, ("tensor above the fixed bf16 bar in the oracle's own self-test, but not on the committed list", key, n_max, n_l2)
+
+
 def _oracle_gate(got, scores, sd, x, mask, cfg, y, keep=None, what="", loss_fn=None, want_dx=False, out_post=None):
     """Compare the output / parameter gradients of the HIP path with the rounding-faithful fp64 oracle at bars derived from
     the oracle's own fp32-vs-fp64 deviation (module docstring).  `loss_fn(out, dtype)`: the objective (default: approxNDCG
@@ -421,9 +453,17 @@ def _oracle_gate(got, scores, sd, x, mask, cfg, y, keep=None, what="", loss_fn=N
         g, n = got[k].double().reshape(want.shape), g_n[k]
         e_max, n_max = _gerr(g, want, gmax), _gerr(n, want, gmax)
         e_l2, n_l2 = _l2err(g, want, gmax), _l2err(n, want, gmax)
-        if e_max > max(2e-2, 4 * n_max):
+        # Bars: max-norm max(2e-2, 2 x self-noise), L2 max(1.5e-2, 1.5 x self-noise) (round 3: 4 x / 2 x) -- the fixed part for every
+        # tensor the oracle's own fp32-accumulation self-test leaves well inside it, the noise-scaled part only where that self-test
+        # itself comes close to or passes the fixed bar (summation order flips bf16 roundings there for ANY implementation: on the
+        # three-block slate-256 golden 24 tensors sit between 2e-2 and 9.2e-2 in the self-test alone).  Tensors the self-test puts
+        # ABOVE the fixed bar are named and must be on the committed list (tests/golden/encoder_noise_scaled.json): a new tensor
+        # drifting up there fails instead of widening its own bar.
+        if n_max > 2e-2 or n_l2 > 1.5e-2:
+            _noise_scaled(what, k, n_max, n_l2, e_max, e_l2)
+        if e_max > max(2e-2, (4 if f"{what}::{k}" in _max_norm_factor_4() else 2) * n_max):
             bad.append((k, "max-norm", e_max, "self-noise", n_max))
-        if e_l2 > max(1.5e-2, 2 * n_l2):
+        if e_l2 > max(1.5e-2, 1.5 * n_l2):
             bad.append((k, "L2", e_l2, "self-noise", n_l2))
         if float(want.abs().max()) >= 0.05 * gmax:
             c, cn = cos(g, want), cos(n, want)
