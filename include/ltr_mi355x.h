@@ -102,6 +102,16 @@ int ltr_lambda_colsum_fwd(const float *scores, const float *labels, int B, int S
 int ltr_lambda_colsum_bwd(const float *scores, const float *labels, int B, int S, int scheme, int k, float sigma,
                           float mu, float eps, float pad, int log_base, const float *grad_colsum, float *dscores,
                           void *stream);
+/* The same column sums for EVERY system of a Lambda-type risk loss in ONE launch (losses/riskLosses/riskLosses.py:63-83, :183-203,
+ * :294-310): system 0 = the model (y_pred), 1..n_base = the baseline rankers (y_base [B][S][n_base], NULL when n_base == 0),
+ * n_base + 1 = the ideal ranking (the labels as scores).  The label vector and every score vector are soft-maxed over the slate first
+ * (:65-70, torch.softmax(dim=1)) inside the kernel.  colsum [n_base + 2][B][S]. */
+int ltr_lambda_colsum_sys_fwd(const float *y_pred, const float *y_true, const float *y_base, int B, int S, int n_base, int scheme,
+                              int k, float sigma, float mu, float eps, float pad, int log_base, float *colsum, void *stream);
+/* Backward of system 0 w.r.t. the RAW y_pred (pair backward on the soft-maxed vectors, then the softmax's Jacobian):
+ * grad_colsum [B][S] = d L / d colsum[0] -> dy_pred [B][S]. */
+int ltr_lambda_colsum_sys_bwd(const float *y_pred, const float *y_true, int B, int S, int scheme, int k, float sigma, float mu,
+                              float eps, float pad, int log_base, const float *grad_colsum, float *dy_pred, void *stream);
 
 /* ---- zRisk / geoRisk(mat, alpha, requires_grad, i)          losses/riskLosses/riskFunctions.py:4-22 / :25-33
  * mat[Q][n_systems]: effectiveness of every system (column) on every query (row); col = the system under test

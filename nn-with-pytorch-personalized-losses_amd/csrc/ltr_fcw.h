@@ -35,7 +35,8 @@
 #endif
 
 #ifndef FCW_X_PREFETCH
-#define FCW_X_PREFETCH 2           // before the dW1 GEMM of a tile: 1 = the next tile's X rows -> registers (68 VGPRs: spills 356 B/lane), 2 = -> L2 only
+#define FCW_X_PREFETCH 0           // before the dW1 GEMM of a tile: 1 = the next tile's X rows -> registers (68 VGPRs: spills 356 B/lane,
+                                   // 19.0 -> 12.1 M slates/s), 2 = -> L2 only (17.7 M); 0 = none: both measured SLOWER (profiles/r04_variant_ab.json)
 #endif
 #ifndef FCW_W1_RELOAD
 #define FCW_W1_RELOAD 1            // exact fp32: the W1 fragments are re-read from L2 per tile (9 KB per wave) instead of pinning 36 VGPRs through

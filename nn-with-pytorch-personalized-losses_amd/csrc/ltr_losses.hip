@@ -332,6 +332,143 @@ lambda_pairs_bwd_kernel(const float *__restrict__ scores, const float *__restric
     }
 }
 
+// ---- Column sums for ALL systems of a Lambda-type risk loss in one launch (riskLosses.py:63-83, :183-203, :294-310): the reference
+// soft-maxes labels, scores and every baseline over the slate (:65-70) and then takes torch.sum(lambdaMask(p, p_true, ...,
+// return_losses=True), dim=1) once per system -- three softmax launches and three column-sum launches here until round 3.  One
+// workgroup per (system, query): system 0 = the model, 1..n = the baselines, n + 1 = the ideal ranking (the labels as scores).
+// v[0..S) -> softmax(v) in place (torch: exp(x - max) / sum); all threads of the block call (barriers inside)
+__device__ __forceinline__ void slate_softmax(const SlateGroup &g, float *v, int S) {
+    float m = -INFINITY;
+    for (int j = g.t; j < S; j += g.group) m = fmaxf(m, v[j]);
+    m = group_max(g, m);
+    float z = 0.f;
+    for (int j = g.t; j < S; j += g.group) {
+        const float e = expf(v[j] - m);
+        v[j] = e;
+        z += e;
+    }
+    z = group_sum(g, z);
+    for (int j = g.t; j < S; j += g.group) v[j] = v[j] / z;
+    __syncthreads();
+}
+
+template <int SCH>
+__global__ void __launch_bounds__(1024)
+lambda_colsum_sys_fwd_kernel(const float *__restrict__ y_pred, const float *__restrict__ y_true, const float *__restrict__ y_base, int B,
+                             int S, int nb, int group, LambdaParams P, float pad, float *__restrict__ colsum) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int s_al = (S + 3) & ~3;
+    const long long blk = ltr_block_id();
+    if (blk >= (long long)(nb + 2) * B) return;  // (whole block: the y-padding of a two-dimensional grid)
+    const int sys = (int)(blk / B);
+    const long long slate = blk - (long long)sys * B;
+    float *base = smem;
+    const LambdaLds L = lambda_carve(base, s_al);
+    int *dar = reinterpret_cast<int *>(base + kLambdaArrays * s_al);   // document at rank r
+    const SlateGroup g = make_group(S, group, base + (kLambdaArrays + 1) * s_al);
+    const size_t off = (size_t)slate * S;
+    for (int j = g.t; j < S; j += group) {
+        L.yl[j] = y_true[off + j];
+        L.sc[j] = sys == 0 ? y_pred[off + j] : (sys <= nb ? y_base[(off + j) * nb + (sys - 1)] : 0.f);
+    }
+    __syncthreads();
+    slate_softmax(g, L.yl, S);
+    if (sys <= nb) slate_softmax(g, L.sc, S);    // (block-uniform)
+    for (int j = g.t; j < S; j += group) {
+        const float pt = L.yl[j];
+        if (sys > nb) L.sc[j] = pt;              // the ideal ranking scores the documents with the (soft-maxed) labels themselves
+        stage_label(pt, pad, L.yl[j], L.gn[j]);
+    }
+    __syncthreads();
+    lambda_prepare(g, L, P);
+    for (int j = g.t; j < S; j += group) dar[L.rk[j]] = j;
+    __syncthreads();
+    float *out = colsum + ((size_t)sys * B + slate) * S;
+    for (int rj = g.t; rj < S; rj += group) {
+        const int j = dar[rj];
+        const bool pj = L.gn[j] < 0.f;
+        const float sj = pj ? -INFINITY : L.sc[j];
+        const float Gj = fmaxf(L.gn[j], 0.f), ycj = fmaxf(L.yl[j], 0.f);
+        float acc = 0.f;
+        for (int ri = 0; ri < S; ++ri) {          // rank order: the order torch.sum(dim=1) walks the column in
+            const int i = dar[ri];
+            const bool pi = L.gn[i] < 0.f;
+            const float si = pi ? -INFINITY : L.sc[i];
+            float d = si - sj;
+            d = (d != d) ? 0.f : fminf(fmaxf(d, -1e8f), 1e8f);
+            float u, um;
+            sigmoid_pair(P.sigma * d, u, um);
+            const float Gi = fmaxf(L.gn[i], 0.f), yci = fmaxf(L.yl[i], 0.f);
+            float ell, dl;
+            lambda_pair_term(P, lambda_weight<SCH>(P, L.delta, L.rk[i], L.rk[j], L.invd[i], L.invd[j], L.w1[i], Gi, Gj, yci, ycj),
+                             u, um, ell, dl);
+            acc += ell;
+        }
+        out[rj] = acc;
+    }
+}
+
+// d L / d y_pred from d L / d colsum[system 0]: the pair backward on the soft-maxed vectors, then the softmax's Jacobian
+// (d p_i / d s_k = p_i (delta_ik - p_k)):  ds_k = p_k (dp_k - sum_i p_i dp_i)
+template <int SCH>
+__global__ void __launch_bounds__(1024)
+lambda_colsum_sys_bwd_kernel(const float *__restrict__ y_pred, const float *__restrict__ y_true, int B, int S, int group, LambdaParams P,
+                             float pad, const float *__restrict__ gup, float *__restrict__ dy_pred) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int s_al = (S + 3) & ~3;
+    const long long slate = ltr_block_id();
+    if (slate >= B) return;
+    float *base = smem;
+    const LambdaLds L = lambda_carve(base, s_al);
+    float *dp = base + kLambdaArrays * s_al;
+    const SlateGroup g = make_group(S, group, dp + s_al);
+    const size_t off = (size_t)slate * S;
+    for (int j = g.t; j < S; j += group) {
+        L.yl[j] = y_true[off + j];
+        L.sc[j] = y_pred[off + j];
+    }
+    __syncthreads();
+    slate_softmax(g, L.yl, S);
+    slate_softmax(g, L.sc, S);
+    for (int j = g.t; j < S; j += group) stage_label(L.yl[j], pad, L.yl[j], L.gn[j]);
+    __syncthreads();
+    lambda_prepare(g, L, P);
+    const float *G = gup + off;
+    for (int i0 = 0; i0 < S; i0 += g.sp) {
+        const int i = i0 + g.ri;
+        const bool row = i < S;
+        const bool vi = row && L.gn[i] >= 0.f;
+        float gr = 0.f;
+        if (vi) {
+            const float si = L.sc[i], Gi = L.gn[i], yci = fmaxf(L.yl[i], 0.f);
+            const int ri = L.rk[i];
+            for (int j = g.cg; j < S; j += g.CG) {
+                const float Gj = L.gn[j];
+                if (j == i || Gj < 0.f) continue;
+                const int rj = L.rk[j];
+                const float draw = si - L.sc[j];
+                if (!(fabsf(draw) <= 1e8f)) continue;
+                float u, um;
+                sigmoid_pair(P.sigma * draw, u, um);
+                const float ycj = fmaxf(L.yl[j], 0.f);
+                float ell, dl_ij, dl_ji;
+                lambda_pair_term(P, lambda_weight<SCH>(P, L.delta, ri, rj, L.invd[i], L.invd[j], L.w1[i], Gi, Gj, yci, ycj),
+                                 u, um, ell, dl_ij);
+                lambda_pair_term(P, lambda_weight<SCH>(P, L.delta, rj, ri, L.invd[j], L.invd[i], L.w1[j], Gj, Gi, ycj, yci),
+                                 um, u, ell, dl_ji);
+                gr += G[rj] * dl_ij - G[ri] * dl_ji;
+            }
+        }
+        const float tot = row_reduce(g, gr);
+        if (row && g.cg == 0) dp[i] = vi ? P.sigma * tot : 0.f;
+    }
+    __syncthreads();
+    float dot = 0.f;
+    for (int j = g.t; j < S; j += group) dot += L.sc[j] * dp[j];
+    dot = group_sum(g, dot);
+    for (int j = g.t; j < S; j += group) dy_pred[off + j] = L.sc[j] * (dp[j] - dot);
+}
+
 // --------------------------------------------------------------------------------------- ordinal
 constexpr int kOrdBlock = 256;
 
@@ -608,6 +745,42 @@ int ltr_lambda_colsum_bwd(const float *scores, const float *labels, int B, int S
     if (int rc = allow_lds(lambda_pairs_bwd_kernel<SCH>, lds)) return rc;                                         \
     hipLaunchKernelGGL(lambda_pairs_bwd_kernel<SCH>, ltr_grid(B), dim3(group), lds, (hipStream_t)stream, scores,      \
                        labels, B, S, group, P, pad, grad_colsum, 1, dscores)
+    LTR_DISPATCH_SCHEME(scheme, CALL)
+#undef CALL
+    return launch_status();
+}
+
+int ltr_lambda_colsum_sys_fwd(const float *y_pred, const float *y_true, const float *y_base, int B, int S, int n_base, int scheme,
+                              int k, float sigma, float mu, float eps, float pad, int log_base, float *colsum, void *stream) {
+    if (int rc = check_slates(y_pred, y_true, colsum, B, S)) return rc;
+    if (n_base < 0 || n_base > 4096 || (n_base > 0 && !y_base)) return n_base > 0 && !y_base ? LTR_ERR_NULL : LTR_ERR_SHAPE;
+    LambdaParams P;
+    if (int rc = make_lambda_params(scheme, k, sigma, mu, eps, log_base, &P)) return rc;
+    if (B == 0) return LTR_OK;
+    const int group = next_pow2(S) < 64 ? 64 : (next_pow2(S) > 1024 ? 1024 : next_pow2(S));
+    const size_t lds = (size_t)((kLambdaArrays + 1) * ((S + 3) & ~3) + group + 32) * sizeof(float);
+#define CALL(SCH)                                                                                                 \
+    if (int rc = allow_lds(lambda_colsum_sys_fwd_kernel<SCH>, lds)) return rc;                                    \
+    hipLaunchKernelGGL(lambda_colsum_sys_fwd_kernel<SCH>, ltr_grid((long long)(n_base + 2) * B), dim3(group), lds, (hipStream_t)stream,   \
+                       y_pred, y_true, y_base, B, S, n_base, group, P, pad, colsum)
+    LTR_DISPATCH_SCHEME(scheme, CALL)
+#undef CALL
+    return launch_status();
+}
+
+int ltr_lambda_colsum_sys_bwd(const float *y_pred, const float *y_true, int B, int S, int scheme, int k, float sigma, float mu,
+                              float eps, float pad, int log_base, const float *grad_colsum, float *dy_pred, void *stream) {
+    if (int rc = check_slates(y_pred, y_true, dy_pred, B, S)) return rc;
+    if (!grad_colsum) return LTR_ERR_NULL;
+    LambdaParams P;
+    if (int rc = make_lambda_params(scheme, k, sigma, mu, eps, log_base, &P)) return rc;
+    if (B == 0) return LTR_OK;
+    const int group = pick_group(S) < 256 ? 256 : pick_group(S);
+    const size_t lds = (size_t)((kLambdaArrays + 1) * ((S + 3) & ~3) + group + 32) * sizeof(float);
+#define CALL(SCH)                                                                                                 \
+    if (int rc = allow_lds(lambda_colsum_sys_bwd_kernel<SCH>, lds)) return rc;                                    \
+    hipLaunchKernelGGL(lambda_colsum_sys_bwd_kernel<SCH>, ltr_grid(B), dim3(group), lds, (hipStream_t)stream, y_pred, y_true, B, S, \
+                       group, P, pad, grad_colsum, dy_pred)
     LTR_DISPATCH_SCHEME(scheme, CALL)
 #undef CALL
     return launch_status();

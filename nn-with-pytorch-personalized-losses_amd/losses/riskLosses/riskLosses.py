@@ -147,6 +147,46 @@ def _lambda_mat(p_true, p_pred, p_base, lt, add_ideal, scheme, ideal_is_ones):
     return mat, False
 
 
+def _lambda_mat_fused(y_predicted, y_true, y_baselines, lt, add_ideal, scheme, ideal_is_ones):
+    """The Lambda-type matrix for the regular shapes in TWO launches: every system's lambdaMask column sums (slate softmaxes
+    inside) -> ltr_lambda_colsum_sys_fwd, then every system's effectiveness -> ltr_risk_matrix_fwd (mode 1).  None for the shapes
+    the tensor-algebra path has to reproduce literally."""
+    reg = _regular(y_predicted, y_true, y_baselines)
+    if reg is None or lt not in (1, 2):
+        return None
+    require_device(y_predicted, y_true)
+    yp, yt, yb = reg
+    cs = _risk.lambda_colsum_systems(yp, yt, yb, scheme)          # [model, baselines..., ideal] x [B, S]
+    nb = cs.shape[0] - 2
+    ones_col = add_ideal == 2 and lt == 2 and ideal_is_ones
+    mat = _risk.risk_matrix(cs[nb + 1], cs[0], cs[1:nb + 1] if nb else None, 1, lt, add_ideal == 2 and not ones_col)
+    if ones_col:
+        mat = torch.cat([mat, torch.ones((mat.shape[0], 1), dtype=mat.dtype, device=mat.device)], 1)        # :106
+    return mat, lt == 1                          # (matrix BEFORE the flip, whether it is flipped: the risk tail does it)
+
+
+def _lambda_loss_fused(kind, y_predicted, y_true, y_baselines, alpha, lt, return_strategy, negative, add_ideal, scheme, ideal_is_ones):
+    """The whole Lambda-type geoRisk / zRisk loss as one autograd node (three launches forward, two backward) for the regular shapes
+    and a plain-number `negative`; None otherwise."""
+    if return_strategy not in (1, 2, 3) or lt not in (1, 2) or isinstance(negative, torch.Tensor):
+        return None
+    reg = _regular(y_predicted, y_true, y_baselines)
+    if reg is None:
+        return None
+    yp, yt, yb = reg
+    ones_col = add_ideal == 2 and lt == 2 and ideal_is_ones
+    return _risk.lambda_risk_loss(yp, yt, yb, scheme, lt, add_ideal == 2 and not ones_col, ones_col, kind, alpha, return_strategy, lt == 1,
+                                  float(negative))
+
+
+def _lambda_matrix(y_predicted, y_true, y_baselines, lt, add_ideal, scheme, ideal_is_ones):
+    fm = _lambda_mat_fused(y_predicted, y_true, y_baselines, lt, add_ideal, scheme, ideal_is_ones)
+    if fm is not None:
+        return fm
+    p_true, p_pred, p_base = _probs(y_predicted, y_true, y_baselines)
+    return _lambda_mat(p_true, p_pred, p_base, lt, add_ideal, scheme, ideal_is_ones)
+
+
 def _tail(kind, mat, flip, alpha, return_strategy, negative, zquirk=False):
     """Flip, risk of the model column (and of the last one), return strategy, `negative`: one launch for a regular fp32 matrix."""
     if return_strategy not in (1, 2, 3):
@@ -200,8 +240,11 @@ def geoRiskListnetLoss(y_predicted, y_true, y_baselines=None, alpha=5, listnet_t
 
 def geoRiskLambdaLoss(y_predicted, y_true, y_baselines=None, alpha=5, listnet_transformation=1, return_strategy=1,
                       negative=1, add_ideal_ranking_to_mat=1, weighing_scheme="ndcgLoss2PP_scheme"):
-    p_true, p_pred, p_base = _probs(y_predicted, y_true, y_baselines)
-    mat, flip = _lambda_mat(p_true, p_pred, p_base, listnet_transformation, add_ideal_ranking_to_mat, weighing_scheme, True)
+    fused = _lambda_loss_fused(_risk.RISK_GEO, y_predicted, y_true, y_baselines, alpha, listnet_transformation, return_strategy, negative,
+                               add_ideal_ranking_to_mat, weighing_scheme, True)
+    if fused is not None:
+        return fused
+    mat, flip = _lambda_matrix(y_predicted, y_true, y_baselines, listnet_transformation, add_ideal_ranking_to_mat, weighing_scheme, True)
     return _tail(_risk.RISK_GEO, mat, flip, alpha, return_strategy, negative)
 
 
@@ -214,8 +257,11 @@ def zRiskListnetLoss(y_predicted, y_true, y_baselines=None, alpha=5, listnet_tra
 
 def zRiskLambdaLoss(y_predicted, y_true, y_baselines=None, alpha=5, listnet_transformation=1, return_strategy=1,
                     negative=1, add_ideal_ranking_to_mat=1, weighing_scheme="ndcgLoss2PP_scheme"):
-    p_true, p_pred, p_base = _probs(y_predicted, y_true, y_baselines)
-    mat, flip = _lambda_mat(p_true, p_pred, p_base, listnet_transformation, add_ideal_ranking_to_mat, weighing_scheme, False)
+    fused = _lambda_loss_fused(_risk.RISK_Z, y_predicted, y_true, y_baselines, alpha, listnet_transformation, return_strategy, negative,
+                               add_ideal_ranking_to_mat, weighing_scheme, False)
+    if fused is not None:
+        return fused
+    mat, flip = _lambda_matrix(y_predicted, y_true, y_baselines, listnet_transformation, add_ideal_ranking_to_mat, weighing_scheme, False)
     return _tail(_risk.RISK_Z, mat, flip, alpha, return_strategy, negative)
 
 

@@ -36,6 +36,8 @@ _PROTOTYPES = {
     "ltr_lambda_colsum_fwd": (c_int, [P, P, c_int, c_int, c_int, c_int, c_float, c_float, c_float, c_float, c_int, P, P]),
     "ltr_lambda_colsum_bwd": (c_int, [P, P, c_int, c_int, c_int, c_int, c_float, c_float, c_float, c_float, c_int,
                                       P, P, P]),
+    "ltr_lambda_colsum_sys_fwd": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, c_float, c_float, c_float, c_float, c_int, P, P]),
+    "ltr_lambda_colsum_sys_bwd": (c_int, [P, P, c_int, c_int, c_int, c_int, c_float, c_float, c_float, c_float, c_int, P, P, P]),
     "ltr_risk_fwd_bwd": (c_int, [P, c_int, c_int, c_int, c_float, c_int, P, P, P]),
     "ltr_trisk_fwd_bwd": (c_int, [P, P, c_int, c_float, P, P, P, P]),
     "ltr_risk_tail_fwd_bwd": (c_int, [P, c_int, c_int, c_float, c_int, c_int, c_int, c_float, c_int, P, P, P]),

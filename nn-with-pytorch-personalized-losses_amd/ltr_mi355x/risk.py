@@ -94,6 +94,101 @@ class LambdaColsum(torch.autograd.Function):
         return (ds.to(ctx.in_dtype),) + (None,) * 8
 
 
+class LambdaColsumSys(torch.autograd.Function):
+    """The lambdaMask column sums of EVERY system of a Lambda-type risk loss in ONE launch (riskLosses.py:63-83, :183-203):
+    [model, baselines..., ideal ranking] x [B, S], with the slate softmaxes of :65-70 inside the kernel -> ltr_lambda_colsum_sys_fwd.
+    Inputs are the RAW y_predicted / y_true [B, S] and y_baselines [B, S, n] (or None); only y_predicted carries a gradient
+    (ltr_lambda_colsum_sys_bwd: pair backward + softmax Jacobian in one launch)."""
+
+    @staticmethod
+    def forward(ctx, y_pred, y_true, y_base, eps, pad, scheme, k, sigma, mu, reduction_log):
+        args = _lambda_args(eps, pad, scheme, k, sigma, mu, reduction_log)
+        B, S = y_pred.shape
+        nb = 0 if y_base is None else int(y_base.shape[2])
+        largs = (args[0], max(args[1], 0)) + args[2:]
+        with torch.cuda.device(y_pred.device):
+            s, y = _f32(y_pred), _f32(y_true)
+            b = None if y_base is None else _f32(y_base)
+            out = torch.empty((nb + 2, B, S), dtype=torch.float32, device=s.device)
+            check(lib().ltr_lambda_colsum_sys_fwd(_ptr(s), _ptr(y), _ptr(b), B, S, nb, *largs, _ptr(out), _stream()),
+                  "ltr_lambda_colsum_sys_fwd")
+        ctx.save_for_backward(s, y)
+        ctx.largs = largs
+        ctx.in_dtype = y_pred.dtype
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        s, y = ctx.saved_tensors
+        B, S = s.shape
+        ds = torch.empty_like(s)
+        with torch.cuda.device(s.device):
+            g0 = g[0].to(torch.float32).contiguous()
+            check(lib().ltr_lambda_colsum_sys_bwd(_ptr(s), _ptr(y), B, S, *ctx.largs, _ptr(g0), _ptr(ds), _stream()),
+                  "ltr_lambda_colsum_sys_bwd")
+        return (ds.to(ctx.in_dtype),) + (None,) * 9
+
+
+class LambdaRiskLoss(torch.autograd.Function):
+    """A whole Lambda-type geoRisk / zRisk loss as ONE autograd node (riskLosses.py:63-125, :183-244): forward = three launches
+    (every system's column sums with the slate softmaxes inside -> every system's effectiveness + d mat[:, 0] / d colsum ->
+    flip + risks + return strategy + d value / d mat), backward = one multiply and ONE launch (pair backward + softmax Jacobian).
+    The chain of separate nodes it replaces cost ~13 launches and as many Python-level autograd hops per step."""
+
+    @staticmethod
+    def forward(ctx, y_pred, y_true, y_base, scheme, lt, ideal, ones_col, kind, alpha, strategy, flip, factor):
+        args = _lambda_args(1e-10, -1, scheme, None, 1., 10., "binary")
+        largs = (args[0], max(args[1], 0)) + args[2:]
+        B, S = y_pred.shape
+        nb = 0 if y_base is None else int(y_base.shape[2])
+        dev = y_pred.device
+        h = lib()
+        with torch.cuda.device(dev):
+            s, y = _f32(y_pred), _f32(y_true)
+            b = None if y_base is None else _f32(y_base)
+            cs = torch.empty((nb + 2, B, S), dtype=torch.float32, device=dev)
+            check(h.ltr_lambda_colsum_sys_fwd(_ptr(s), _ptr(y), _ptr(b), B, S, nb, *largs, _ptr(cs), _stream()), "ltr_lambda_colsum_sys_fwd")
+            nsys = 1 + nb + (1 if ideal else 0)
+            mat = torch.empty((B, nsys + (1 if ones_col else 0)), dtype=torch.float32, device=dev)
+            m0 = mat if not ones_col else torch.empty((B, nsys), dtype=torch.float32, device=dev)
+            jac = torch.empty((B, S), dtype=torch.float32, device=dev)
+            check(h.ltr_risk_matrix_fwd(_ptr(cs[nb + 1]), _ptr(cs[0]), _ptr(cs[1:nb + 1]) if nb else None, B, S, nb, 1, int(lt), int(bool(ideal)),
+                                        _ptr(m0), _ptr(jac), _stream()), "ltr_risk_matrix_fwd")
+            if ones_col:
+                mat[:, :nsys] = m0
+                mat[:, nsys] = 1.0                                   # the ideal ranking's cosine with itself (:106)
+            out = torch.empty(1, dtype=torch.float32, device=dev)
+            dmat = torch.empty_like(mat)
+            check(h.ltr_risk_tail_fwd_bwd(_ptr(mat), B, mat.shape[1], float(alpha), int(kind), int(strategy), int(bool(flip)), float(factor), 0,
+                                          _ptr(out), _ptr(dmat), _stream()), "ltr_risk_tail_fwd_bwd")
+            g0 = jac.mul_(dmat[:, 0:1])                              # d value / d colsum[model]
+        ctx.save_for_backward(s, y, g0)
+        ctx.largs = largs
+        ctx.in_dtype = y_pred.dtype
+        return out
+
+    @staticmethod
+    def backward(ctx, go):
+        s, y, g0 = ctx.saved_tensors
+        B, S = s.shape
+        ds = torch.empty_like(s)
+        with torch.cuda.device(s.device):
+            g = g0 * go.to(torch.float32)
+            check(lib().ltr_lambda_colsum_sys_bwd(_ptr(s), _ptr(y), B, S, *ctx.largs, _ptr(g), _ptr(ds), _stream()), "ltr_lambda_colsum_sys_bwd")
+        return (ds.to(ctx.in_dtype),) + (None,) * 11
+
+
+def lambda_risk_loss(y_pred, y_true, y_base, scheme, lt, ideal, ones_col, kind, alpha, strategy, flip, factor):
+    require_device(y_pred, y_true)
+    return LambdaRiskLoss.apply(y_pred, y_true, y_base, scheme, lt, ideal, ones_col, kind, alpha, strategy, flip, factor)
+
+
+def lambda_colsum_systems(y_pred, y_true, y_base, weighing_scheme, eps=1e-10, padded_value_indicator=-1, k=None, sigma=1., mu=10.,
+                          reduction_log="binary"):
+    require_device(y_pred, y_true)
+    return LambdaColsumSys.apply(y_pred, y_true, y_base, eps, padded_value_indicator, weighing_scheme, k, sigma, mu, reduction_log)
+
+
 class RiskMatrix(torch.autograd.Function):
     """The [queries, systems] effectiveness matrix of the risk-sensitive losses in ONE launch (riskLosses.py:8-49, :63-117) ->
     ltr_risk_matrix_fwd: column 0 the model (`x0`, the only input that carries a gradient), then the baselines (`rest`), optionally
