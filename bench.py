@@ -144,7 +144,7 @@ def secondary_lines(a):
       f16x2  : the f16 x 2 split-precision variant of the pipeline (same C ABI, LTR_LIB; parity-green at the fp32 bars) on the
                headline workload -- reported next to the exact-fp32 headline, not instead of it;
       two64  : the 136-64-1 two-layer scorer BASELINE.json configs[0] names, the configuration the 60 % HBM target was
-               written for (exact-fp32 library);
+               written for (exact-fp32 library); two64_f16x2: the same on the split-precision variant;
       config5: BASELINE.json configs[4] -- architeture/transformer.py scorer (make_model: FC 136->128, 6 encoder blocks,
                8 heads, d_ff 2048, dropout 0.1) + approxNDCG, slate 256, bf16 operands (tools/bench_encoder.py)."""
     import subprocess
@@ -153,7 +153,8 @@ def secondary_lines(a):
     base = [sys.executable, here, "--steps", str(a.steps), "--warmup", str(a.warmup), "--queries", str(a.queries), "--slate",
             str(a.slate), "--batch", str(a.batch), "--no-cpu-baseline", "--no-extras"]
     runs = {"f16x2": (base + ["--net", "double"], {"LTR_LIB": variant} if os.path.exists(variant) else None),
-            "two64": (base + ["--net", "two64"], {})}
+            "two64": (base + ["--net", "two64"], {}),
+            "two64_f16x2": (base + ["--net", "two64"], {"LTR_LIB": variant} if os.path.exists(variant) else None)}
     out = {}
     for name, (cmd, env_add) in runs.items():
         if env_add is None:
@@ -165,7 +166,9 @@ def secondary_lines(a):
             j = json.loads(line)
             out[name] = {"value": j["value"], "unit": j["unit"], "ms_per_step": j["ms_per_step"], "workload": j["config"]["workload"],
                          "roofline": {k: j["roofline"][k] for k in ("achieved", "frac", "kernel_ms", "hbm_achieved_GBps", "hbm_frac_of_8TBps")}}
-            if name == "f16x2":
+            if j["roofline"].get("traffic") is not None:
+                out[name]["roofline"]["traffic"] = j["roofline"]["traffic"]
+            if name in ("f16x2", "two64_f16x2"):
                 out[name]["library"] = "libltr_mi355x_f16x2.so (LTR_LIB): fp32 operands as two f16 pieces on the f16 matrix cores, fp32 accumulation"
                 out[name]["roofline"]["note"] = ("achieved / frac: algorithmic fp32 FLOP/s over the fp32-MFMA peak (157.3 TF) the exact library is "
                                                  "bound by -- this variant issues 4 f16 piece products per fp32 product on the 2.5 PF f16 pipe")

@@ -93,10 +93,11 @@ __device__ __forceinline__ float approx_ndcg_slate(const SlateGroup &g, float *s
                                                    float gscale, bool want_grad, Store store, Stamp stamp = Stamp(),
                                                    ApproxScratch xs = ApproxScratch()) {
     const int s_al = (g.S + 3) & ~3;
-    // contiguous column block of this column group, multiple of 4
-    const int jb = JB > 0 ? JB : ((((g.S + g.CG - 1) / g.CG) + 3) & ~3);
-    const int j0 = g.cg * jb;
-    const int j1 = JB > 0 ? j0 + JB : min(j0 + jb, s_al);
+    // column QUADS interleaved between the CG lanes of a row (lane cg takes quads cg, cg + CG, ...): the CG broadcast addresses of one
+    // ds_read_b128 then sit 16 bytes apart instead of a whole column block apart (= the same banks: a CG-way conflict, 131 M conflict
+    // cycles per 100 k slates at S = 128, profiles/r04_rocprof_pmc_summaries.json).  (JB: kept for callers that name a block length.)
+    const int nq = s_al >> 2, qs = 4 * g.CG;        // quads per row; column stride between a lane's quads
+    const int jq0 = 4 * g.cg;                       // this lane's first column
     const bool ultra_ok = xs.um != nullptr && eps <= 1e-7f;
     int *bins = reinterpret_cast<int *>(g.part + 32);
 
@@ -172,15 +173,15 @@ __device__ __forceinline__ float approx_ndcg_slate(const SlateGroup &g, float *s
                     return fmaf(fmaf(N01, D23, N23 * D01), ltr_rcp(D01 * D23), acc);
                 };
                 float acc0 = 0.f, acc1 = 0.f;
-                int j = j0;
+                int j = jq0;
 #pragma unroll UNR
-                for (; j + 8 <= j1; j += 8) {
+                for (; j + qs < s_al; j += 2 * qs) {
                     acc0 = quad(j, acc0);
-                    acc1 = quad(j + 4, acc1);
+                    acc1 = quad(j + qs, acc1);
                 }
-                if (j < j1) acc0 = quad(j, acc0);
+                if (j < s_al) acc0 = quad(j, acc0);
                 p = acc0 + acc1;
-                if (i >= j0 && i < j1) p -= 0.5f;                                               // the j == i term: u_i / (2 u_i)
+                if (((i >> 2) & (g.CG - 1)) == g.cg) p -= 0.5f;                                 // the j == i term: u_i / (2 u_i)
             }
             // ideal-DCG term of RANK i from the label histogram: the document at sorted position i has the label v with
             // (#labels > v) <= i < (#labels >= v); labels 0 carry no gain
@@ -199,7 +200,7 @@ __device__ __forceinline__ float approx_ndcg_slate(const SlateGroup &g, float *s
             const float yi = yl[i];
             float c0 = 0.f, c1 = 0.f, c2 = 0.f, c3 = 0.f;
 #pragma unroll 2
-            for (int j = j0; j < j1; j += 4) {
+            for (int j = jq0; j < s_al; j += qs) {
                 const lds_f4 y = *reinterpret_cast<const lds_f4 *>(yl + j);
                 c0 += ((y[0] > yi) || (y[0] == yi && j + 0 < i)) ? 1.f : 0.f;
                 c1 += ((y[1] > yi) || (y[1] == yi && j + 1 < i)) ? 1.f : 0.f;
@@ -213,7 +214,7 @@ __device__ __forceinline__ float approx_ndcg_slate(const SlateGroup &g, float *s
                 const float ui = uu[i];
                 float p0 = 0.f, p1 = 0.f, p2 = 0.f, p3 = 0.f;
 #pragma unroll 2
-                for (int j = j0; j < j1; j += 4) {
+                for (int j = jq0; j < s_al; j += qs) {
                     const lds_f4 u = *reinterpret_cast<const lds_f4 *>(uu + j);
                     const lds_f4 m = *reinterpret_cast<const lds_f4 *>(mk + j);
                     p0 = fmaf(m[0], fmaxf(u[0] * ltr_rcp(ui + u[0]), eps), p0);
@@ -222,14 +223,17 @@ __device__ __forceinline__ float approx_ndcg_slate(const SlateGroup &g, float *s
                     p3 = fmaf(m[3], fmaxf(u[3] * ltr_rcp(ui + u[3]), eps), p3);
                 }
                 p = (p0 + p1) + (p2 + p3);
-                if (i >= j0 && i < j1) p -= fmaxf(ui * ltr_rcp(ui + ui), eps);   // the j == i term
+                if (((i >> 2) & (g.CG - 1)) == g.cg) p -= fmaxf(ui * ltr_rcp(ui + ui), eps);   // the j == i term
             } else {
                 const float si = sc[i];
-                for (int j = j0; j < j1; ++j) {
-                    const float e = __expf(alpha * (si - sc[j]));
-                    const float c = fmaxf(ltr_rcp(1.f + e), eps);
-                    p += (j != i && mk[j] != 0.f) ? c : 0.f;
-                }
+                for (int j4 = jq0; j4 < s_al; j4 += qs)
+#pragma unroll
+                    for (int e4 = 0; e4 < 4; ++e4) {
+                        const int j = j4 + e4;
+                        const float e = __expf(alpha * (si - sc[j]));
+                        const float c = fmaxf(ltr_rcp(1.f + e), eps);
+                        p += (j != i && mk[j] != 0.f) ? c : 0.f;
+                    }
             }
         }
         }
@@ -298,13 +302,13 @@ __device__ __forceinline__ float approx_ndcg_slate(const SlateGroup &g, float *s
                 return fmaf(fmaf(N01, Q23, N23 * Q01), ltr_rcp(Q01 * Q23), acc);
             };
             float acc0 = 0.f, acc1 = 0.f;
-            int j = j0;
+            int j = jq0;
 #pragma unroll UNR
-            for (; j + 8 <= j1; j += 8) {
+            for (; j + qs < s_al; j += 2 * qs) {
                 acc0 = quad(j, acc0);
-                acc1 = quad(j + 4, acc1);
+                acc1 = quad(j + qs, acc1);
             }
-            if (j < j1) acc0 = quad(j, acc0);
+            if (j < s_al) acc0 = quad(j, acc0);
             a = uk * (acc0 + acc1);
         } else if (vk) {
             const float gk = gg[k];
@@ -312,7 +316,7 @@ __device__ __forceinline__ float approx_ndcg_slate(const SlateGroup &g, float *s
                 const float uk = uu[k];
                 float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
 #pragma unroll 2
-                for (int j = j0; j < j1; j += 4) {
+                for (int j = jq0; j < s_al; j += qs) {
                     const lds_f4 u = *reinterpret_cast<const lds_f4 *>(uu + j);
                     const lds_f4 m = *reinterpret_cast<const lds_f4 *>(mk + j);
                     const lds_f4 gj = *reinterpret_cast<const lds_f4 *>(gg + j);
@@ -329,13 +333,16 @@ __device__ __forceinline__ float approx_ndcg_slate(const SlateGroup &g, float *s
                 a = (a0 + a1) + (a2 + a3);      // j == k contributes exactly 0 (term = g_k - g_k)
             } else {
                 const float sk = sc[k];
-                for (int j = j0; j < j1; ++j) {
-                    const float e = __expf(alpha * (sk - sc[j]));
-                    const float ckj = ltr_rcp(1.f + e);                 // sigmoid(-alpha (s_k - s_j))
-                    const float cjk = (e < 1e30f) ? e * ckj : 1.f;        // sigmoid(-alpha (s_j - s_k))
-                    const float term = (cjk >= eps ? gg[j] : 0.f) - (ckj >= eps ? gk : 0.f);
-                    a += (j != k && mk[j] != 0.f) ? ckj * cjk * term : 0.f;
-                }
+                for (int j4 = jq0; j4 < s_al; j4 += qs)
+#pragma unroll
+                    for (int e4 = 0; e4 < 4; ++e4) {
+                        const int j = j4 + e4;
+                        const float e = __expf(alpha * (sk - sc[j]));
+                        const float ckj = ltr_rcp(1.f + e);                 // sigmoid(-alpha (s_k - s_j))
+                        const float cjk = (e < 1e30f) ? e * ckj : 1.f;        // sigmoid(-alpha (s_j - s_k))
+                        const float term = (cjk >= eps ? gg[j] : 0.f) - (ckj >= eps ? gk : 0.f);
+                        a += (j != k && mk[j] != 0.f) ? ckj * cjk * term : 0.f;
+                    }
             }
         }
         const float tot = row_reduce(g, a);

@@ -135,7 +135,7 @@ def test_block_on_its_own_matches_the_reference_module(case):
         gate = _composite_gate(case, g, mod, ins, out, pairs, w_out)
         ledger_record(f"block {case['id']} worst gradient vs rounding-faithful oracle (max-norm)", gate["max"], noise=gate["noise_max"],
                       tol=max(2e-2, 4 * gate["noise_max"]), note=note + f"; min cosine {gate['min_cos']:.6f}")
-        ledger_record(f"block {case['id']} worst gradient vs the reference module (ledger only, not a gate)", worst, tol=1.0, note=note)
+        ledger_record(f"block {case['id']} worst gradient vs the reference module (ledger only, not a gate)", worst, tol=1.0, note=note, asserted=False)
     else:
         assert worst_cos > 0.999, worst_cos
         ledger_record(f"block {case['id']} worst gradient (max-norm)", worst, tol=tol_g, note=note + f"; min cosine {worst_cos:.6f}")

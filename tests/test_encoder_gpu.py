@@ -513,7 +513,7 @@ def test_network_vs_reference_golden(case):
     ledger_record("encoder worst param-grad vs rounding-faithful oracle (L2)", gate["l2"], noise=gate["noise_l2"],
                   tol=max(1.5e-2, 2 * gate["noise_l2"]), note=note)
     ledger_record("encoder scores vs reference fp32 (ledger only)", relerr(scores.detach().cpu().numpy(), want_s), tol=3e-2, note=note)
-    ledger_record("encoder worst param-grad vs reference fp32 (ledger only, not a gate)", loose, tol=1.0,
+    ledger_record("encoder worst param-grad vs reference fp32 (ledger only, not a gate)", loose, tol=1.0, asserted=False,
                   note=note + f"; whole-gradient cosine {cos:.5f}")
 
 
@@ -562,7 +562,7 @@ def test_benched_config5_network_vs_reference_golden():
     note = "benched config-5 network (3.6 M parameters) vs the reference's fp32 CPU run; bf16 bars (tests/test_encoder_gpu.py)"
     assert worst_norm < 5e-2, worst_norm
     ledger_record("config-5 network scores vs reference fp32", e_s, tol=3e-2, note=note)
-    ledger_record("config-5 network worst param-grad vs reference fp32 (stored rows; ledger only)", worst, tol=1.0, note=note)
+    ledger_record("config-5 network worst param-grad vs reference fp32 (stored rows; ledger only)", worst, tol=1.0, note=note, asserted=False)
     ledger_record("config-5 network worst matrix-gradient norm deviation vs reference fp32", worst_norm, tol=5e-2, note=note)
     ledger_record("config-5 network worst param-grad vs rounding-faithful oracle (max-norm)", gate["max"], noise=gate["noise_max"],
                   tol=max(2e-2, 4 * gate["noise_max"]), note=note + f"; min cosine {gate['min_cos']:.6f}")
