@@ -25,6 +25,16 @@ extern "C" {
 /* fp32 -> bf16 (round to nearest even), n elements.  Used once per step on the master weights. */
 int ltr_enc_cast_bf16(const float *src, uint16_t *dst, int64_t n, void *stream);
 
+/* Device-side dropout epoch.  Every kernel of this file draws its masks from (seed + EPOCH, stream_id, index), where EPOCH is a
+ * 64-bit word in device memory (0 after load).  The reference draws a new mask per forward from torch's generator
+ * (architeture/transformer.py:30,52,161 -- nn.Dropout); a host passes a new `seed` per step for that.  A launch sequence recorded
+ * into a hipGraph has its `seed` arguments frozen, so it begins with ltr_enc_seed_advance (a kernel node): each replay then uses
+ * the next epoch, forward and backward of the same replay the same one.  All three are stream-ordered like any other launch;
+ * ltr_enc_seed_get synchronises the device (tests). */
+int ltr_enc_seed_set(uint64_t value, void *stream);
+int ltr_enc_seed_advance(uint64_t delta, void *stream);
+int ltr_enc_seed_get(uint64_t *value);
+
 /* out[i] = 1 if element i of `stream_id` is kept (see the header comment), i in [0, n). */
 int ltr_enc_dropout_mask(uint64_t seed, int stream_id, int64_t n, float p, uint8_t *out, void *stream);
 /* The keep mask of the attention-probability dropout (transformer.py:161-163), out [B][h][S][S]. */
@@ -143,36 +153,6 @@ int ltr_enc_score_fwd(const float *x, const float *a, const float *b, const floa
 /* dx [T][d] (overwritten) and per-workgroup partials [nblk][3*d + 8]: d a_2 | d b_2 | d w | d bias (1 float, padded). */
 int ltr_enc_score_bwd(const float *x, const float *a, const float *b, const float *w, const float *dscores, int64_t T, int d,
                       float eps, int norm, float *dx, float *partials, int nblk, void *stream);
-
-/* ---- The same tail FUSED with approxNDCGLoss (losses/approxNDCG.py:7-53) and both backwards, one workgroup per slate:
- * scores and d loss / d scores live in LDS only (BASELINE config 5: "MFMA attention path + LDS loss fused").
- *   labels [B][S] (pad marks padded documents), slate_loss [B] (caller averages), scores [B][S] optional (NULL),
- *   dx [B*S][d] = grad_scale * d slate_loss / d x, partials [B][3*d + 8] as ltr_enc_score_bwd (one row per slate). */
-int ltr_enc_tail_approxndcg(const float *x, const float *a, const float *b, const float *w, const float *bias, const float *labels,
-                            int B, int S, int d, float ln_eps, int norm, float alpha, float eps, float pad, float grad_scale,
-                            float *slate_loss, float *scores, float *dx, float *partials, void *stream);
-
-/* ---- The whole network in two calls (csrc/ltr_encoder_host.hip): the launch sequence of LTRModel.forward / backward
- * (multiLayer.py:74-81) issued from C++.  `params` / `grads`: host arrays of n_params device pointers (fp32) in this order:
- *   [input_norm.weight, input_norm.bias]                       if input_norm
- *   fc[i].weight [out][in], fc[i].bias                         per FC layer
- *   per encoder block: norm1.a_2, norm1.b_2, Wq, bq, Wk, bk, Wv, bv, Wo, bo, norm2.a_2, norm2.b_2, W1, b1, W2, b2
- *   encoder.norm.a_2, encoder.norm.b_2                         if has_encoder
- *   output w_1.weight [1][d_model], w_1.bias [1]
- * `workspace`: ltr_enc_workspace_bytes(spec, B, S) bytes, 256-byte aligned, untouched between the forward and its
- * backward (it holds the saved activations).  `mask` [B][S] uint8, 1 = padded document (required with an encoder).
- * ltr_enc_backward overwrites every grads[i] with d (sum_t dscores[t] * scores[t]) / d params[i]. */
-#define LTR_ENC_MAX_FC 8
-typedef struct ltr_enc_spec {
-    int32_t n_features, n_fc, fc_sizes[LTR_ENC_MAX_FC], input_norm, has_encoder, n_layers, heads, d_ff;
-    float fc_dropout, enc_dropout;
-} ltr_enc_spec;
-int64_t ltr_enc_workspace_bytes(const ltr_enc_spec *spec, int B, int S);      /* < 0: LTR_ERR_* */
-int ltr_enc_forward(const ltr_enc_spec *spec, const float *x, const uint8_t *mask, int B, int S, const float *const *params,
-                    int n_params, uint64_t seed, int training, void *workspace, float *scores, void *stream);
-int ltr_enc_backward(const ltr_enc_spec *spec, const float *x, const uint8_t *mask, int B, int S, const float *const *params,
-                     int n_params, uint64_t seed, int training, const float *dscores, void *workspace, float *const *grads,
-                     void *stream);
 
 #ifdef __cplusplus
 }

@@ -113,22 +113,13 @@ class LTRModel(nn.Module):
         if self.output_layer.d_output != 1:
             return self.output_layer(self.prepare_for_output(x, mask, indices))
         spec = self._ltr_spec(x.shape[-1])
-        fn = _enc.EncoderScoresNative if _enc.native_enabled(spec) else _enc.EncoderScores
-        return fn.apply(spec, x, mask, self._ltr_next_seed(), self.training, *self._ltr_params())
+        return _enc.EncoderScores.apply(spec, x, mask, self._ltr_next_seed(), self.training, *self._ltr_params())
 
     def score(self, x, mask, indices):
         """multiLayer.py:83-91: scores [batch, slate] (outputs summed when d_output > 1)."""
         if self.output_layer.d_output != 1:
             return self.output_layer.score(self.prepare_for_output(x, mask, indices))
         return self.forward(x, mask, indices)
-
-    def ltr_approx_ndcg_loss(self, x, mask, y_true, eps=1e-10, padded_value_indicator=-1, alpha=1.):
-        """NOT part of the reference's surface: `approxNDCGLoss(self(x, mask, None), y_true, ...)`
-        as ONE autograd node -- the scoring tail, the listwise loss and both backwards run in one kernel per slate with
-        the scores in LDS only (BASELINE config 5).  Same value and gradients as the two-call form."""
-        spec = self._ltr_spec(x.shape[-1])
-        return _enc.EncoderApproxNDCG.apply(spec, x, mask, y_true, self._ltr_next_seed(), self.training, eps, padded_value_indicator,
-                                            alpha, *self._ltr_params())
 
 
 def _as_kwargs(cfg):

@@ -61,12 +61,22 @@ __device__ __forceinline__ unsigned mix32(unsigned h) {
 // TWO 32-bit keys per (seed, stream): k0 is xored into the counter, k1 is ADDED between the two multiplies of the finaliser, so the
 // streams of two (seed, stream) pairs are not XOR-translations of one fixed sequence (they would be with a single key folded in
 // in front: mask_A[i] == mask_B[i ^ delta]).  Both are wave-uniform and hoisted out of every loop; the cost is one add per word.
+// DEVICE-SIDE EPOCH: every kernel adds the 64-bit word g_drop_epoch to the seed it was launched with.  The word lives in device
+// memory and only ltr_enc_seed_set / ltr_enc_seed_advance (one-thread kernels on the caller's stream) write it, so a launch
+// sequence recorded ONCE into a hipGraph (kernel arguments frozen, seed included) draws fresh masks on every replay when the
+// graph begins with an advance node.  0 (the value after load) leaves the stream of a seed exactly what it was.  Read through the
+// constant address space: invariant for the duration of a kernel, one scalar load, hoisted out of every loop like the keys.
+__device__ unsigned long long g_drop_epoch = 0ull;
+__device__ __forceinline__ unsigned long long drop_seed(unsigned long long seed) {
+    return seed + *(const __attribute__((address_space(4))) unsigned long long *)(&g_drop_epoch);
+}
 __device__ __forceinline__ unsigned drop_key0(unsigned long long seed, int stream_id) {
-    return mix32((unsigned)seed ^ (0x9E3779B9u * (unsigned)(stream_id + 1)));
+    return mix32((unsigned)drop_seed(seed) ^ (0x9E3779B9u * (unsigned)(stream_id + 1)));
 }
 __device__ __forceinline__ unsigned drop_key1(unsigned long long seed, int stream_id) {
-    return mix32((unsigned)(seed >> 32) + 0x85EBCA6Bu * (unsigned)stream_id + 0x165667B1u);
+    return mix32((unsigned)(drop_seed(seed) >> 32) + 0x85EBCA6Bu * (unsigned)stream_id + 0x165667B1u);
 }
+__global__ void seed_epoch_kernel(unsigned long long v, int add) { g_drop_epoch = add ? g_drop_epoch + v : v; }
 __device__ __forceinline__ unsigned drop_word(unsigned long long seed, int stream_id, unsigned long long quad) {
     unsigned h = (unsigned)quad ^ drop_key0(seed, stream_id) ^ (0x27D4EB2Fu * (unsigned)(quad >> 32));
     h ^= h >> 16; h *= 0x85EBCA6Bu; h += drop_key1(seed, stream_id); h ^= h >> 13; h *= 0xC2B2AE35u; h ^= h >> 16;
@@ -517,240 +527,6 @@ score_bwd_kernel(const float *__restrict__ x, const float *__restrict__ a, const
     block_cols_out(db, d, red, out + d);
     block_cols_out(dw, d, red, out + 2 * d);
     block_cols_out(dbias, 1, red, out + 3 * d);
-}
-
-// ------------------------------------------------------------------------------------------- scoring tail + LDS loss
-// Encoder.norm + OutputLayer.w_1 + approxNDCGLoss (losses/approxNDCG.py:7-53) + their backward in ONE kernel, one
-// workgroup per slate: (1) scores of the slate's documents (one wave per document, as score_fwd_kernel) go to LDS,
-// (2) the listwise loss runs on them in LDS (approx_ndcg_slate, the device function of the standalone loss kernel),
-// its d loss / d scores stay in LDS, (3) every document is read once more (L2-hot) for the backward through w_1 and the
-// norm: dx, and this slate's partial sums of d a_2, d b_2, d w, d bias.  scores / dscores never touch HBM (the scores
-// are optionally written for callers that want them).
-__global__ void __launch_bounds__(1024)
-tail_approxndcg_kernel(const float *__restrict__ x, const float *__restrict__ a, const float *__restrict__ b,
-                       const float *__restrict__ wv, const float *__restrict__ bias, const float *__restrict__ labels, int S,
-                       int group, int d, float ln_eps, int norm, float alpha, float eps, float pad, float gscale,
-                       float *__restrict__ slate_loss, float *__restrict__ scores_out, float *__restrict__ dxo,
-                       float *__restrict__ partials) {
-    extern __shared__ __attribute__((aligned(16))) float tsm[];
-    const int s_al = (S + 3) & ~3, nw = group / 64;
-    float *sc = tsm, *yl = sc + s_al, *gn = yl + s_al, *gg = gn + s_al, *uu = gg + s_al, *mk = uu + s_al;
-    float *scratch = mk + s_al;                       // [group + 32] for the slate group
-    float *ds = scratch + group + 32;                 // [s_al] d loss / d score
-    float *red = ds + s_al;                           // [nw][d] cross-wave column sums
-    const ltr::SlateGroup g = ltr::make_group(S, group, scratch);
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const long long t0 = (long long)blockIdx.x * S;
-    float aw[kLnMax], bw = 0.f;
-#pragma unroll
-    for (int j = 0; j < kLnMax; ++j) {
-        const int f = lane + 64 * j;
-        const float wj = f < d ? wv[f] : 0.f;
-        aw[j] = norm ? (f < d ? a[f] * wj : 0.f) : wj;
-        bw += (norm && f < d) ? b[f] * wj : 0.f;
-    }
-    bw = wave_sum(bw) + bias[0];
-    for (int i = w; i < S; i += nw) {
-        float v[kLnMax];
-#pragma unroll
-        for (int j = 0; j < kLnMax; ++j) v[j] = (lane + 64 * j < d) ? x[(t0 + i) * d + lane + 64 * j] : 0.f;
-        float sdot = 0.f;
-        if (norm) {
-            const LnStats st = ln_stats(v, d, lane, ln_eps, norm == 2);
-#pragma unroll
-            for (int j = 0; j < kLnMax; ++j) sdot += (lane + 64 * j < d) ? aw[j] * (v[j] - st.mean) * st.r : 0.f;
-        } else {
-#pragma unroll
-            for (int j = 0; j < kLnMax; ++j) sdot += aw[j] * v[j];
-        }
-        sdot = wave_sum(sdot) + bw;
-        if (lane == 0) {
-            sc[i] = sdot;
-            if (scores_out) scores_out[t0 + i] = sdot;
-        }
-    }
-    for (int j = g.t; j < S; j += group) ltr::stage_label(labels[t0 + j], pad, yl[j], gn[j]);
-    __syncthreads();
-    const float loss = ltr::approx_ndcg_slate(g, sc, yl, gn, gg, uu, mk, alpha, eps, gscale, true, [&](int i, float v) { ds[i] = v; });
-    if (threadIdx.x == 0) slate_loss[blockIdx.x] = loss;
-    __syncthreads();
-    float wj[kLnMax], av[kLnMax], bv[kLnMax], da[kLnMax], db[kLnMax], dw[kLnMax];
-    float dbias = 0.f;
-#pragma unroll
-    for (int j = 0; j < kLnMax; ++j) {
-        const int f = lane + 64 * j;
-        wj[j] = f < d ? wv[f] : 0.f;
-        av[j] = (norm && f < d) ? a[f] : 0.f;
-        bv[j] = (norm && f < d) ? b[f] : 0.f;
-        da[j] = db[j] = dw[j] = 0.f;
-    }
-    for (int i = w; i < S; i += nw) {
-        const float g0 = ds[i];
-        float v[kLnMax];
-#pragma unroll
-        for (int j = 0; j < kLnMax; ++j) v[j] = (lane + 64 * j < d) ? x[(t0 + i) * d + lane + 64 * j] : 0.f;
-        dbias += g0;
-        if (norm) {
-            const LnStats st = ln_stats(v, d, lane, ln_eps, norm == 2);
-            float c[kLnMax], gv[kLnMax], dx[kLnMax];
-#pragma unroll
-            for (int j = 0; j < kLnMax; ++j) {
-                c[j] = (lane + 64 * j < d) ? v[j] - st.mean : 0.f;
-                const float xh = c[j] * st.r, dyj = g0 * wj[j];
-                dw[j] += g0 * (av[j] * xh + bv[j]);
-                da[j] += dyj * xh;
-                db[j] += dyj;
-                gv[j] = dyj * av[j];
-            }
-            ln_dx(c, gv, st, d, lane, norm == 2, dx);
-#pragma unroll
-            for (int j = 0; j < kLnMax; ++j)
-                if (lane + 64 * j < d) dxo[(t0 + i) * d + lane + 64 * j] = dx[j];
-        } else {
-#pragma unroll
-            for (int j = 0; j < kLnMax; ++j) {
-                dw[j] += g0 * v[j];
-                if (lane + 64 * j < d) dxo[(t0 + i) * d + lane + 64 * j] = g0 * wj[j];
-            }
-        }
-    }
-    // this slate's column sums: waves added in index order
-    float *out = partials + (long long)blockIdx.x * (3 * d + 8);
-    for (int which = 0; which < 3; ++which) {
-        __syncthreads();
-#pragma unroll
-        for (int j = 0; j < kLnMax; ++j)
-            if (lane + 64 * j < d) red[w * d + lane + 64 * j] = which == 0 ? da[j] : (which == 1 ? db[j] : dw[j]);
-        __syncthreads();
-        for (int f = threadIdx.x; f < d; f += group) {
-            float sacc = 0.f;
-            for (int k = 0; k < nw; ++k) sacc += red[k * d + f];
-            out[which * d + f] = sacc;
-        }
-    }
-    __syncthreads();
-    if (lane == 0) red[w] = dbias;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        float sacc = 0.f;
-        for (int k = 0; k < nw; ++k) sacc += red[k];
-        out[3 * d] = sacc;
-    }
-}
-
-// 32 lanes x 4 consecutive features per document, two documents per wave (d <= 128, d % 4 == 0): statistics of one
-// document from its lane's 4 values
-struct TokStats { float mean, r, sigma; };
-__device__ __forceinline__ float half_sum(float v) {
-#pragma unroll
-    for (int o = 16; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
-}
-__device__ __forceinline__ TokStats tok_stats(const f32x4 &v, bool in, int d, float eps, int standard, f32x4 &c) {
-    TokStats st;
-    st.mean = half_sum((v[0] + v[1]) + (v[2] + v[3])) / (float)d;
-    c = v - st.mean;
-    if (!in) c = f32x4{0.f, 0.f, 0.f, 0.f};
-    const float q = half_sum((c[0] * c[0] + c[1] * c[1]) + (c[2] * c[2] + c[3] * c[3]));
-    if (standard) { st.sigma = sqrtf(q / (float)d + eps); st.r = 1.f / st.sigma; }
-    else { st.sigma = sqrtf(q / (float)(d - 1)); st.r = 1.f / (st.sigma + eps); }
-    return st;
-}
-
-__global__ void __launch_bounds__(1024)
-tail_approxndcg_v4_kernel(const float *__restrict__ x, const float *__restrict__ a, const float *__restrict__ b,
-                          const float *__restrict__ wv, const float *__restrict__ bias, const float *__restrict__ labels, int S,
-                          int group, int d, float ln_eps, int norm, float alpha, float eps, float pad, float gscale,
-                          float *__restrict__ slate_loss, float *__restrict__ scores_out, float *__restrict__ dxo,
-                          float *__restrict__ partials) {
-    extern __shared__ __attribute__((aligned(16))) float tsm[];
-    const int s_al = (S + 3) & ~3, nw = group / 64;
-    float *sc = tsm, *yl = sc + s_al, *gn = yl + s_al, *gg = gn + s_al, *uu = gg + s_al, *mk = uu + s_al;
-    float *scratch = mk + s_al, *ds = scratch + group + 32, *red = ds + s_al;       // red: [2 nw][3][128] + [2 nw]
-    const ltr::SlateGroup g = ltr::make_group(S, group, scratch);
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, half = lane >> 5, f0 = 4 * (lane & 31);
-    const bool in = f0 < d;
-    const long long t0 = (long long)blockIdx.x * S;
-    f32x4 av = {0.f, 0.f, 0.f, 0.f}, bv = av, wj = av;
-    if (in) {
-        wj = *reinterpret_cast<const f32x4 *>(wv + f0);
-        if (norm) {
-            av = *reinterpret_cast<const f32x4 *>(a + f0);
-            bv = *reinterpret_cast<const f32x4 *>(b + f0);
-        }
-    }
-    const f32x4 aw = norm ? av * wj : wj;
-    const float bw = (norm ? half_sum((bv[0] * wj[0] + bv[1] * wj[1]) + (bv[2] * wj[2] + bv[3] * wj[3])) : 0.f) + bias[0];
-    for (int i = 2 * w + half; i < S; i += 2 * nw) {
-        f32x4 v = {0.f, 0.f, 0.f, 0.f}, c;
-        if (in) v = *reinterpret_cast<const f32x4 *>(x + (t0 + i) * d + f0);
-        float sdot;
-        if (norm) {
-            const TokStats st = tok_stats(v, in, d, ln_eps, norm == 2, c);
-            sdot = ((aw[0] * c[0] + aw[1] * c[1]) + (aw[2] * c[2] + aw[3] * c[3])) * st.r;
-        } else sdot = (aw[0] * v[0] + aw[1] * v[1]) + (aw[2] * v[2] + aw[3] * v[3]);
-        sdot = half_sum(sdot) + bw;
-        if ((lane & 31) == 0) {
-            sc[i] = sdot;
-            if (scores_out) scores_out[t0 + i] = sdot;
-        }
-    }
-    for (int j = g.t; j < S; j += group) ltr::stage_label(labels[t0 + j], pad, yl[j], gn[j]);
-    __syncthreads();
-    const float loss = ltr::approx_ndcg_slate(g, sc, yl, gn, gg, uu, mk, alpha, eps, gscale, true, [&](int i, float v) { ds[i] = v; });
-    if (threadIdx.x == 0) slate_loss[blockIdx.x] = loss;
-    __syncthreads();
-    f32x4 da = {0.f, 0.f, 0.f, 0.f}, db = da, dw = da;
-    float dbias = 0.f;
-    for (int i = 2 * w + half; i < S; i += 2 * nw) {
-        const float g0 = ds[i];
-        f32x4 v = {0.f, 0.f, 0.f, 0.f}, c;
-        if (in) v = *reinterpret_cast<const f32x4 *>(x + (t0 + i) * d + f0);
-        dbias += g0;
-        f32x4 dx;
-        if (norm) {
-            const TokStats st = tok_stats(v, in, d, ln_eps, norm == 2, c);
-            const f32x4 xh = c * st.r, dy = wj * g0;
-            dw += (av * xh + bv) * g0;
-            da += dy * xh;
-            db += dy;
-            const f32x4 gv = dy * av;
-            const float sg = half_sum((gv[0] + gv[1]) + (gv[2] + gv[3]));
-            const float sgc = half_sum((gv[0] * c[0] + gv[1] * c[1]) + (gv[2] * c[2] + gv[3] * c[3]));
-            const float mg = sg / (float)d;
-            const float k2 = norm == 2 ? st.r * st.r * st.r * sgc / (float)d
-                                       : (st.sigma > 0.f ? st.r * st.r * sgc / ((float)(d - 1) * st.sigma) : 0.f);
-            dx = (gv - mg) * st.r - c * k2;
-        } else {
-            dw += v * g0;
-            dx = wj * g0;
-        }
-        if (in) *reinterpret_cast<f32x4 *>(dxo + (t0 + i) * d + f0) = dx;
-    }
-    // this slate's column sums over its 2 nw (wave, half) rows, in index order
-    float *row = red + (2 * w + half) * 384;
-    if (in) {
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            row[f0 + k] = da[k];
-            row[128 + f0 + k] = db[k];
-            row[256 + f0 + k] = dw[k];
-        }
-    }
-    if ((lane & 31) == 0) red[2 * nw * 384 + 2 * w + half] = dbias;
-    __syncthreads();
-    float *out = partials + (long long)blockIdx.x * (3 * d + 8);
-    for (int f = threadIdx.x; f < 3 * d; f += group) {
-        const int which = f / d, col = f - which * d;
-        float sacc = 0.f;
-        for (int k = 0; k < 2 * nw; ++k) sacc += red[k * 384 + which * 128 + col];
-        out[f] = sacc;
-    }
-    if (threadIdx.x == 0) {
-        float sacc = 0.f;
-        for (int k = 0; k < 2 * nw; ++k) sacc += red[2 * nw * 384 + k];
-        out[3 * d] = sacc;
-    }
 }
 
 // ------------------------------------------------------------------------------------------- column sums
@@ -2243,6 +2019,20 @@ int ltr_enc_cast_bf16(const float *src, uint16_t *dst, int64_t n, void *stream) 
     return status();
 }
 
+int ltr_enc_seed_set(uint64_t value, void *stream) {
+    hipLaunchKernelGGL(seed_epoch_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, (unsigned long long)value, 0);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+int ltr_enc_seed_advance(uint64_t delta, void *stream) {
+    hipLaunchKernelGGL(seed_epoch_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, (unsigned long long)delta, 1);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+int ltr_enc_seed_get(uint64_t *value) {
+    unsigned long long v = 0;
+    if (hipMemcpyFromSymbol(&v, HIP_SYMBOL(g_drop_epoch), sizeof(v), 0, hipMemcpyDeviceToHost) != hipSuccess) return -2;
+    *value = (uint64_t)v;
+    return 0;
+}
 int ltr_enc_dropout_mask(uint64_t seed, int stream_id, int64_t n, float p, uint8_t *out, void *stream) {
     if (!out) return LTR_ERR_NULL;
     if (n < 0) return LTR_ERR_SHAPE;
@@ -2463,37 +2253,6 @@ int ltr_enc_ffn_bwd_w(const uint16_t *n2, const uint16_t *w1, const float *b1, c
     static bool d64[64] = {}, d128[64] = {};
     if (d == 64) return ffn_launch(ffn_bwd_w_kernel<64>, d64, grid, 2 * 2 * 128 * (64 + 16) * sizeof(bf16_t), a, (hipStream_t)stream);
     return ffn_launch(ffn_bwd_w_kernel<128>, d128, grid, (2 * 128 * (128 + 16) + 2 * 128 * 128) * sizeof(bf16_t), a, (hipStream_t)stream);
-}
-
-int ltr_enc_tail_approxndcg(const float *x, const float *a, const float *b, const float *w, const float *bias, const float *labels,
-                            int B, int S, int d, float ln_eps, int norm, float alpha, float eps, float pad, float grad_scale,
-                            float *slate_loss, float *scores, float *dx, float *partials, void *stream) {
-    if (!x || !w || !bias || !labels || !slate_loss || !dx || !partials || (norm && (!a || !b))) return LTR_ERR_NULL;
-    if (B < 0 || S < 1 || S > LTR_MAX_SLATE || d < 2 || d > 64 * kLnMax) return LTR_ERR_SHAPE;
-    if (norm < 0 || norm > 2) return LTR_ERR_PARAM;
-    if (B == 0) return LTR_OK;
-    const int group = ltr::pick_group(S), s_al = (S + 3) & ~3, nw = group / 64;
-    const bool v4 = d <= 128 && d % 4 == 0 && !(((uintptr_t)x | (uintptr_t)w | (uintptr_t)a | (uintptr_t)b | (uintptr_t)dx) & 15u);
-    const size_t red = v4 ? (size_t)2 * nw * 385 : (size_t)(nw * d > nw ? nw * d : nw);
-    const size_t lds = (size_t)(7 * s_al + group + 32 + red) * sizeof(float);
-    if (lds > 160 * 1024) return LTR_ERR_SHAPE;
-    static bool done[64] = {};
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = -1;
-    if (dev < 0 || !done[dev]) {
-        hipError_t e = hipFuncSetAttribute((const void *)tail_approxndcg_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e == hipSuccess)
-            e = hipFuncSetAttribute((const void *)tail_approxndcg_v4_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) return (int)e;
-        if (dev >= 0) done[dev] = true;
-    }
-    if (v4)
-        hipLaunchKernelGGL(tail_approxndcg_v4_kernel, dim3(B), dim3(group), lds, (hipStream_t)stream, x, a, b, w, bias, labels, S, group,
-                           d, ln_eps, norm, alpha, eps, pad, grad_scale, slate_loss, scores, dx, partials);
-    else
-        hipLaunchKernelGGL(tail_approxndcg_kernel, dim3(B), dim3(group), lds, (hipStream_t)stream, x, a, b, w, bias, labels, S, group, d,
-                           ln_eps, norm, alpha, eps, pad, grad_scale, slate_loss, scores, dx, partials);
-    return status();
 }
 
 int ltr_enc_score_fwd(const float *x, const float *a, const float *b, const float *w, const float *bias, int64_t T, int d,

@@ -48,6 +48,9 @@ _PROTOTYPES = {
     "ltr_gather_rows_f32": (c_int, [P, c_int64, P, c_int64, c_int64, P, P]),
     # include/ltr_encoder.h (row f-3)
     "ltr_enc_cast_bf16": (c_int, [P, P, c_int64, P]),
+    "ltr_enc_seed_set": (c_int, [c_uint64, P]),
+    "ltr_enc_seed_advance": (c_int, [c_uint64, P]),
+    "ltr_enc_seed_get": (c_int, [ctypes.POINTER(c_uint64)]),
     "ltr_enc_dropout_mask": (c_int, [c_uint64, c_int, c_int64, c_float, P, P]),
     "ltr_enc_attn_dropout_mask": (c_int, [c_uint64, c_int, c_int, c_int, c_int, c_float, P, P]),
     "ltr_enc_sum_partials": (c_int, [P, c_int, c_int64, c_int, P, P]),
@@ -66,11 +69,6 @@ _PROTOTYPES = {
     "ltr_enc_ffn_fwd": (c_int, [P, P, P, P, P, P, c_int64, c_int, c_int, c_float, c_uint64, c_int, c_int, P, P]),
     "ltr_enc_ffn_bwd_x": (c_int, [P, P, P, P, P, c_int64, c_int, c_int, c_float, c_uint64, c_int, P, P]),
     "ltr_enc_ffn_bwd_w": (c_int, [P, P, P, P, P, c_int64, c_int, c_int, c_float, c_uint64, c_int, c_int, P, P, P, P]),
-    "ltr_enc_tail_approxndcg": (c_int, [P, P, P, P, P, P, c_int, c_int, c_int, c_float, c_int, c_float, c_float, c_float, c_float,
-                                        P, P, P, P, P]),
-    "ltr_enc_workspace_bytes": (c_int64, [P, c_int, c_int]),
-    "ltr_enc_forward": (c_int, [P, P, P, c_int, c_int, P, c_int, c_uint64, c_int, P, P, P]),
-    "ltr_enc_backward": (c_int, [P, P, P, c_int, c_int, P, c_int, c_uint64, c_int, P, P, P, P]),
     "ltr_enc_score_fwd": (c_int, [P, P, P, P, P, c_int64, c_int, c_float, c_int, P, P]),
     "ltr_enc_score_bwd": (c_int, [P, P, P, P, P, c_int64, c_int, c_float, c_int, P, P, c_int, P]),
     "ltr_ordinal_num_blocks": (c_int64, [c_int64]),

@@ -94,6 +94,22 @@ def sum_partials(parts, nsplit, n, out=None, accumulate=False):
     return out
 
 
+def seed_set(value):
+    """Set the device-side dropout epoch (added to every launch's seed; include/ltr_encoder.h) on the current stream."""
+    check(lib().ltr_enc_seed_set(int(value) & (2 ** 64 - 1), _stream()), "ltr_enc_seed_set")
+
+
+def seed_advance(delta=1):
+    """epoch += delta as a kernel on the current stream: the first node of a captured training step (graphs.GraphedTrainStep)."""
+    check(lib().ltr_enc_seed_advance(int(delta) & (2 ** 64 - 1), _stream()), "ltr_enc_seed_advance")
+
+
+def seed_get():
+    v = ctypes.c_uint64(0)
+    check(lib().ltr_enc_seed_get(ctypes.byref(v)), "ltr_enc_seed_get")
+    return int(v.value)
+
+
 def dropout_mask(seed, stream_id, n, p, device):
     out = torch.empty(n, dtype=torch.uint8, device=device)
     check(lib().ltr_enc_dropout_mask(int(seed), int(stream_id), n, float(p), _ptr(out), _stream()), "ltr_enc_dropout_mask")
@@ -467,144 +483,6 @@ def _body_backward(spec, seed, st, dx, want_dx=False):
         grads[0], grads[1] = layernorm_bwd(st["xin"], prm[0], dx, T, F, STD_LN_EPS, 1, scratch)
         dx = scratch
     return grads, (dx if want_dx else None)
-
-
-class EncSpec(ctypes.Structure):
-    """struct ltr_enc_spec of include/ltr_encoder.h."""
-    _fields_ = [("n_features", ctypes.c_int32), ("n_fc", ctypes.c_int32), ("fc_sizes", ctypes.c_int32 * 8),
-                ("input_norm", ctypes.c_int32), ("has_encoder", ctypes.c_int32), ("n_layers", ctypes.c_int32),
-                ("heads", ctypes.c_int32), ("d_ff", ctypes.c_int32), ("fc_dropout", ctypes.c_float), ("enc_dropout", ctypes.c_float)]
-
-
-def _c_spec(spec):
-    c = EncSpec()
-    c.n_features, c.n_fc = spec.n_features, len(spec.fc_sizes)
-    for i, v in enumerate(spec.fc_sizes):
-        c.fc_sizes[i] = v
-    c.input_norm, c.has_encoder, c.n_layers = int(spec.input_norm), int(spec.has_encoder), spec.n_layers
-    c.heads, c.d_ff, c.fc_dropout, c.enc_dropout = spec.heads, spec.d_ff, spec.fc_dropout, spec.enc_dropout
-    return c
-
-
-def native_enabled(spec):
-    """LTR_ENC_NATIVE=1 selects the C++ orchestrator (csrc/ltr_encoder_host.hip: one FFI call per forward / backward
-    instead of ~450; bit-identical results).  Off by default: measured on the MI355X it is 2 % slower at 256 slates per
-    step (7.71 vs 7.57 ms: per-tensor weight casts, no allocator reuse of hot buffers) and equal at 16-64 slates, where
-    the step is bound by the GPU-side dispatch of ~450 small kernels, not by Python.  It is the entry point for
-    non-Python hosts."""
-    import os
-    return os.environ.get("LTR_ENC_NATIVE", "0") == "1" and len(spec.fc_sizes) <= 8
-
-
-class EncoderScoresNative(torch.autograd.Function):
-    """EncoderScores with the launch sequence issued from C++ (ltr_enc_forward / ltr_enc_backward)."""
-
-    @staticmethod
-    def forward(ctx, spec, x, mask, seed, training, *params):
-        if len(params) != spec.n_params():
-            raise ValueError(f"expected {spec.n_params()} parameter tensors, got {len(params)}")
-        require_device(x, *params)
-        if x.dim() != 3 or x.shape[2] != spec.n_features:
-            raise ValueError(f"input must be [batch, slate, {spec.n_features}], got {tuple(x.shape)}")
-        B, S, F = x.shape
-        if spec.has_encoder and S > 512:
-            raise ValueError("the attention kernels hold a whole slate: slate_length <= 512")
-        if spec.has_encoder and mask is None:
-            raise AttributeError("'NoneType' object has no attribute 'unsqueeze'")      # transformer.py:55
-        if params[-2].shape[0] != 1:
-            raise NotImplementedError("OutputLayer with d_output > 1 is not built on the HIP path")
-        ctx.param_dtypes = [p.dtype for p in params]
-        ctx.shapes = [tuple(p.shape) for p in params]
-        if B * S == 0:
-            ctx.ws = None
-            return torch.empty((B, S), dtype=torch.float32, device=x.device)
-        dev = x.device
-        with torch.cuda.device(dev):
-            cs = _c_spec(spec)
-            nbytes = lib().ltr_enc_workspace_bytes(ctypes.byref(cs), B, S)
-            if nbytes < 0:
-                check(int(nbytes), "ltr_enc_workspace_bytes")
-            ws = torch.empty(nbytes + 256, dtype=torch.uint8, device=dev)
-            ws_ptr = (ws.data_ptr() + 255) & ~255
-            xin = x.detach().to(torch.float32).contiguous()
-            prm = [p.detach().to(torch.float32).contiguous() for p in params]
-            pp = (ctypes.c_void_p * len(prm))(*[p.data_ptr() for p in prm])
-            mask_u8 = (mask.to(dev) == 1).to(torch.uint8).contiguous() if spec.has_encoder else None
-            scores = torch.empty((B, S), dtype=torch.float32, device=dev)
-            check(lib().ltr_enc_forward(ctypes.byref(cs), _ptr(xin), _ptr(mask_u8), B, S, pp, len(prm), int(seed) & (2 ** 64 - 1),
-                                        int(bool(training)), ws_ptr, _ptr(scores), _stream()), "ltr_enc_forward")
-        ctx.spec, ctx.cs, ctx.seed, ctx.training = spec, cs, int(seed) & (2 ** 64 - 1), bool(training)
-        ctx.ws, ctx.ws_ptr, ctx.xin, ctx.prm, ctx.mask_u8, ctx.dims = ws, ws_ptr, xin, prm, mask_u8, (B, S)
-        return scores
-
-    @staticmethod
-    def backward(ctx, dscores):
-        dev = dscores.device
-        if ctx.ws is None:
-            zeros = [torch.zeros(sh, dtype=dt, device=dev) for sh, dt in zip(ctx.shapes, ctx.param_dtypes)]
-            return (None, None, None, None, None, *zeros)
-        B, S = ctx.dims
-        prm = ctx.prm
-        with torch.cuda.device(dev):
-            ds = dscores.detach().to(torch.float32).contiguous()
-            sizes = [(p.numel() + 63) // 64 * 64 for p in prm]                    # 256-byte aligned pieces of one buffer
-            flat = torch.empty(sum(sizes), dtype=torch.float32, device=dev)
-            offs = [0]
-            for n in sizes:
-                offs.append(offs[-1] + n)
-            gviews = [flat[o:o + p.numel()].view(p.shape) for o, p in zip(offs, prm)]
-            pp = (ctypes.c_void_p * len(prm))(*[p.data_ptr() for p in prm])
-            gp = (ctypes.c_void_p * len(prm))(*[g.data_ptr() for g in gviews])
-            check(lib().ltr_enc_backward(ctypes.byref(ctx.cs), _ptr(ctx.xin), _ptr(ctx.mask_u8), B, S, pp, len(prm), ctx.seed,
-                                         int(ctx.training), _ptr(ds), ctx.ws_ptr, gp, _stream()), "ltr_enc_backward")
-        out = [g.to(dt) for g, dt in zip(gviews, ctx.param_dtypes)]
-        return (None, None, None, None, None, *out)
-
-
-class EncoderApproxNDCG(torch.autograd.Function):
-    """The whole network AND approxNDCGLoss (losses/approxNDCG.py:7-53) as one autograd node: the scoring tail, the
-    listwise loss and their backward run in one kernel per slate with scores / d scores in LDS only
-    (ltr_enc_tail_approxndcg) -- BASELINE config 5's "attention path + LDS loss fused".  Returns the mean slate loss."""
-
-    @staticmethod
-    def forward(ctx, spec, x, mask, y_true, seed, training, eps, pad, alpha, *params):
-        if len(params) != spec.n_params():
-            raise ValueError(f"expected {spec.n_params()} parameter tensors, got {len(params)}")
-        require_device(x, y_true, *params)
-        if x.dim() != 3 or tuple(y_true.shape[:2]) != tuple(x.shape[:2]) or x.shape[0] * x.shape[1] == 0:
-            raise ValueError(f"x [B, S, F] and y_true [B, S] with B, S >= 1 expected, got {tuple(x.shape)} / {tuple(y_true.shape)}")
-        ctx.param_dtypes = [p.dtype for p in params]
-        with torch.cuda.device(x.device):
-            st = _run_forward(spec, x, mask, seed, training, params)
-            B, S, _ = st["dims"]
-            T, d, prm = B * S, spec.d_model, st["prm"]
-            if prm[-2].shape[0] != 1:
-                raise NotImplementedError("OutputLayer with d_output > 1 is not built on the HIP path")
-            fa, fb = (prm[-4], prm[-3]) if spec.has_encoder else (None, None)
-            labels = y_true.detach().to(torch.float32).contiguous().view(B, S)
-            slate_loss = torch.empty(B, dtype=torch.float32, device=x.device)
-            dx = torch.empty((T, d), dtype=torch.float32, device=x.device)
-            parts = torch.empty((B, 3 * d + 8), dtype=torch.float32, device=x.device)
-            check(lib().ltr_enc_tail_approxndcg(_ptr(st["final_x"]), _ptr(fa), _ptr(fb), _ptr(prm[-2]), _ptr(prm[-1]), _ptr(labels), B, S, d,
-                                                LN_EPS, 1 if spec.has_encoder else 0, float(alpha), float(eps), float(pad), 1.0 / B,
-                                                _ptr(slate_loss), None, _ptr(dx), _ptr(parts), _stream()), "ltr_enc_tail_approxndcg")
-            loss = torch.empty((), dtype=torch.float32, device=x.device)
-            check(lib().ltr_reduce_sum_f32(_ptr(slate_loss), B, 1.0 / B, _ptr(loss), _stream()), "ltr_reduce_sum_f32")
-            ctx.tail = sum_partials(parts, B, 3 * d + 8)
-        ctx.spec, ctx.seed, ctx.st, ctx.dx = spec, int(seed), st, dx
-        return loss
-
-    @staticmethod
-    def backward(ctx, go):
-        st = ctx.st
-        with torch.cuda.device(go.device):
-            with deferred_reductions():
-                # the backward accumulates into its dx argument in place: hand it a copy, so that a second backward over
-                # the same graph (retain_graph=True / gradient accumulation over one forward) starts from the tail's dx again
-                grads = _with_tail(ctx.spec, _body_backward(ctx.spec, ctx.seed, st, ctx.dx.clone())[0], ctx.tail)
-            scale = go.detach().to(torch.float32)
-            out = [None if g is None else (g * scale).to(dt).reshape(p.shape) for g, dt, p in zip(grads, ctx.param_dtypes, st["prm"])]
-        return (None, None, None, None, None, None, None, None, None, *out)
 
 
 def encoder_features(spec, x, mask, seed, training, params):

@@ -644,73 +644,6 @@ def test_network_api_errors_and_features(enc):
         make_model(dict(sizes=[30], input_norm=False, activation=None, dropout=0.0), None, dict(d_output=1), 16).to(DEV)(x, None, None)
 
 
-@pytest.mark.parametrize("with_encoder", [True, False])
-def test_fused_tail_loss_matches_the_two_call_form(enc, with_encoder):
-    """LTRModel.ltr_approx_ndcg_loss (tail + loss + backward in one kernel per slate, scores in LDS) vs
-    approxNDCGLoss(net(x, mask, None), y): same forward tensors, so the loss and the tail's gradients agree to fp32 rounding
-    and everything behind the first bf16 cast of the backward to bf16 rounding."""
-    from architeture.multiLayer import make_model
-    from losses.approxNDCG import approxNDCGLoss
-    import copy
-    torch.manual_seed(9)
-    fc = dict(sizes=[64], input_norm=False, activation=None, dropout=0.0)
-    tr = dict(N=2, d_ff=128, h=4, dropout=0.1, positional_encoding=None) if with_encoder else None
-    net = make_model(copy.deepcopy(fc), copy.deepcopy(tr), dict(d_output=1), 136).to(DEV).train()
-    for B, S in ((5, 100), (3, 256), (2, 7)):
-        x = torch.randn(B, S, 136, device=DEV)
-        y = torch.randint(0, 5, (B, S), device=DEV).float()
-        mask = torch.zeros(B, S, dtype=torch.bool, device=DEV)
-        mask[0, S - 2:] = True
-        y[mask] = -1
-        net.ltr_seed, net._ltr_calls = 11, 0
-        net.zero_grad()
-        la = approxNDCGLoss(net(x, mask, None), y)
-        la.backward()
-        ga = {k: p.grad.clone() for k, p in net.named_parameters()}
-        net.ltr_seed, net._ltr_calls = 11, 0            # same dropout streams
-        net.zero_grad()
-        lb = net.ltr_approx_ndcg_loss(x, mask, y)
-        (2.0 * lb).backward()                            # grad_output is honoured
-        assert abs(float(la) - float(lb)) <= 1e-5 * abs(float(la))
-        gmax = max(float(v.abs().max()) for v in ga.values())
-        for k, p in net.named_parameters():
-            tail = k.startswith("output_layer.") or k.startswith("encoder.norm.")
-            # (the key-projection bias has a zero true gradient -- rounding noise: floor on the scale, as elsewhere)
-            e = float((0.5 * p.grad - ga[k]).abs().max()) / max(float(ga[k].abs().max()), (1e-3 if tail else 0.05) * gmax)
-            # the tail's own parameters: fp32 summation order only.  Everything below it sees d loss / d x through a bf16
-            # rounding (ltr_enc_drop_cast_colsum): the two tails' last-bit differences flip a few roundings (2^-9 each)
-            assert e < (2e-4 if tail else 3e-2), (B, S, k, e)
-
-
-@pytest.mark.parametrize("fc,tr", [
-    (dict(sizes=[128], input_norm=False, activation=None, dropout=0.1), dict(N=2, d_ff=256, h=8, dropout=0.1, positional_encoding=None)),
-    (dict(sizes=[48, 40], input_norm=True, activation=None, dropout=0.2), dict(N=1, d_ff=64, h=5, dropout=0.1, positional_encoding=None)),
-    (None, dict(N=2, d_ff=64, h=8, dropout=0.0, positional_encoding=None)),
-    (dict(sizes=[32, 16], input_norm=True, activation=None, dropout=0.0), None)])
-def test_native_orchestrator_matches_python_path(enc, fc, tr):
-    """ltr_enc_forward / ltr_enc_backward (launch sequence issued from C++) vs the Python-driven sequence: the same
-    kernels with the same arguments in the same order, so scores and every gradient are bit-identical."""
-    from architeture.multiLayer import make_model
-    import copy
-    torch.manual_seed(21)
-    net = make_model(copy.deepcopy(fc), copy.deepcopy(tr), dict(d_output=1), 136).to(DEV).train()
-    spec, params = net._ltr_spec(136), net._ltr_params()
-    for B, S in ((3, 100), (2, 256), (1, 5)):
-        x = torch.randn(B, S, 136, device=DEV)
-        mask = torch.zeros(B, S, dtype=torch.bool, device=DEV)
-        mask[0, S - 1] = True
-        w = torch.randn(B, S, device=DEV)
-        outs = []
-        for fn in (enc.EncoderScores, enc.EncoderScoresNative):
-            net.zero_grad()
-            s_ = fn.apply(spec, x, mask if tr else None, 4242, True, *params)
-            (s_ * w).sum().backward()
-            outs.append((s_.detach().clone(), [p.grad.clone() for p in params]))
-        assert torch.equal(outs[0][0], outs[1][0])
-        for k, (ga, gb) in enumerate(zip(outs[0][1], outs[1][1])):
-            assert torch.equal(ga, gb), (B, S, k, float((ga - gb).abs().max()))
-
-
 def test_network_edge_shapes(enc):
     """Empty batch, one-document slates, tiny and ragged slate lengths, every mask dtype the callers use."""
     import ltr_encoder_oracle as EO

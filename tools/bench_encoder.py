@@ -38,9 +38,11 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--dropout", type=float, default=0.1)
-    ap.add_argument("--fused-tail", action="store_true",
-                    help="LTRModel.ltr_approx_ndcg_loss (scoring tail + LDS loss + backward in one kernel per slate) instead of "
-                         "approxNDCGLoss(net(x, mask, None), y); measured ~3 %% slower at 256 slates per step (one workgroup per slate)")
+    ap.add_argument("--graph", action="store_true",
+                    help="the whole step (seed advance + forward + loss + backward + Adam) as ONE hipGraph (graphs.GraphedTrainStep)")
+    ap.add_argument("--adam", choices=["foreach", "fused"], default="fused",
+                    help="torch.optim.Adam implementation: fused = one multi-tensor kernel; foreach (torch's default) is ~25 launches eager and, "
+                         "with capturable=True, ~230 (202 of them 0-dim divisions) -- rounds 2-3 measured foreach")
     a = ap.parse_args()
     from architeture.multiLayer import make_model
     from losses.approxNDCG import approxNDCGLoss
@@ -53,7 +55,7 @@ def main():
                      dict(d_output=1, output_activation=None), F).to(dev)
     net.train()
     d = fc[-1] if fc else F
-    opt = torch.optim.Adam(net.parameters(), lr=1e-4)
+    opt = torch.optim.Adam(net.parameters(), lr=1e-4, capturable=a.graph, fused=(a.adam == "fused"))
     B, S = a.batch, a.slate
     x = torch.randn(B, S, F, device=dev)
     y = torch.randint(0, 5, (B, S), device=dev).float()
@@ -61,11 +63,17 @@ def main():
 
     def step():
         opt.zero_grad(set_to_none=True)
-        loss = net.ltr_approx_ndcg_loss(x, mask, y) if a.fused_tail else approxNDCGLoss(net(x, mask, None), y)
+        loss = approxNDCGLoss(net(x, mask, None), y)
         loss.backward()
         opt.step()
         return loss
 
+    if a.graph:
+        from ltr_mi355x.graphs import GraphedTrainStep
+        graphed = GraphedTrainStep(net, opt, lambda n, x, m, y: approxNDCGLoss(n(x, m, None), y), (x, mask, y))
+
+        def step():                                  # noqa: F811
+            return graphed(x, mask, y)
     for _ in range(a.warmup):
         step()
     torch.cuda.synchronize()
@@ -76,8 +84,9 @@ def main():
     dt = (time.perf_counter() - t0) / a.steps
     fl = flops_per_slate(S, F, fc, d, a.heads, a.dff, a.layers)
     print(json.dumps({"workload": f"approxNDCG + make_model(fc={fc}, N={a.layers}, h={a.heads}, d_ff={a.dff}, dropout={a.dropout}) "
-                                  f"train mode, {B} slates x {S} x {F} per step, fwd+loss+bwd+Adam, "
-                                  + ("scoring tail fused with the LDS loss" if a.fused_tail else "scores -> loss as two autograd nodes"),
+                                  f"train mode, {B} slates x {S} x {F} per step, fwd+loss+bwd+Adam({a.adam}), "
+                                  + ("replayed as one hipGraph (device-side dropout epoch)" if a.graph else "eager launches"),
+                      "graph": bool(a.graph),
                       "slates_per_s": round(B / dt, 1), "ms_per_step": round(dt * 1e3, 3), "flops_per_slate": fl,
                       "tflops": round(B * fl / dt / 1e12, 2), "frac_of_bf16_mfma_peak": round(B * fl / dt / 2.5e15, 4),
                       "final_loss": round(float(loss.detach()), 5), "max_mem_GB": round(torch.cuda.max_memory_allocated() / 2 ** 30, 2)}))
