@@ -743,18 +743,9 @@ __device__ __forceinline__ void dma_x_rows(const PipeArgs &a, float *Xs, long lo
 }
 
 #include "ltr_fcw.h"
-// The weights-stationary kernel for the live DoubleLayerNet (ltr_wst.h): correct (the whole fused test matrix
-// passes with it) but SLOWER than the generic pipeline on this chip -- 0.567 of the fp32 MFMA peak (8 waves) / 0.529 (4 waves, 512
-// registers) against 0.612 -- so it is an opt-in build (-DLTR_WST=1, tools/build_variant.sh), not part of the shipped libraries.
-#ifndef LTR_WST
-#define LTR_WST 0
-#endif
-#if LTR_WST
-#ifndef WST_WAVES
-#define WST_WAVES 8
-#endif
-#include "ltr_wst.h"
-#endif
+// A weights-stationary kernel for the live DoubleLayerNet was built and measured in round 4: parity-green but
+// slower than this pipeline (0.567 of the fp32 MFMA peak against 0.612), so it is not in the tree; its source is csrc/ltr_wst.h at
+// commit 139af5e, its measurements profiles/r04_wst_weights_stationary_experiment.json.
 
 // ST (MODE_FUSED with approxNDCG only): 128 = the slate length is the compile-time constant 128 (the kernel then carries ONE copy
 // of the loss: three copies cost the 136-wide kernel 180 B/lane of scratch); 0 = a.S at run time.
@@ -1578,14 +1569,6 @@ int pipeline_dispatch(int mode, const PipeArgs &a, int grid, hipStream_t stream)
                     case 1: return launch_fcw<N, 1>(a, grid, stream);
                     default: return launch_fcw<N, 2>(a, grid, stream);
                 }
-#if LTR_WST
-            } else if constexpr (std::is_same<N, DoubleNet>::value) {
-                switch (a.loss_kind) {       // the live DoubleLayerNet: weights-stationary kernel, one workgroup per CU
-                    case 0: return launch_wst<N, 0>(a, grid, stream);
-                    case 1: return launch_wst<N, 1>(a, grid, stream);
-                    default: return launch_wst<N, 2>(a, grid, stream);
-                }
-#endif
             } else {
                 switch (a.loss_kind) {
                     case 0:

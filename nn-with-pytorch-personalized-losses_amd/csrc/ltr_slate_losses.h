@@ -353,8 +353,45 @@ __device__ __forceinline__ float approx_ndcg_slate(const SlateGroup &g, float *s
 }
 
 // invd[r] = 1 / log2(2 + r), r < n: the rank discounts of the ideal DCG (approxNDCG.py:41-43), same expression as the per-row epilogue
+// invd[n + c - 1] = sum_{r < c} invd[r], c = 1 .. n: the discount mass of the first c positions (ideal_dcg_by_counts below).
 __device__ __forceinline__ void ltr_fill_inv_discount(float *invd, int n, int tid, int nthreads) {
-    for (int r = tid; r < n; r += nthreads) invd[r] = ltr_rcp(__log2f(2.f + (float)r));
+    for (int r = tid; r < n; r += nthreads) {
+        invd[r] = ltr_rcp(__log2f(2.f + (float)r));
+        float cum = 0.f;
+        for (int q = 0; q <= r; ++q) cum += ltr_rcp(__log2f(2.f + (float)q));      // once per kernel
+        invd[n + r] = cum;
+    }
+}
+
+// Ideal DCG of a slate with integer grades 0 .. 15 (gain 2^y - 1; approxNDCG.py:38-43), WITHOUT sorting and without a per-grade
+// placement pass: the gain of grade y is the sum of the increments 2^(w-1), w = 1 .. y, and increment w applies to every
+// document with a grade >= w -- in the descending order those are the FIRST c_w = #{labels >= w} positions.  Hence
+//     idcg = sum_w 2^(w-1) D[c_w],   D[c] = sum_{r < c} 1 / log2(2 + r)   (table dcum[c - 1], ltr_fill_inv_discount).
+// Per grade present: one ballot + popcount per slot and one v_writelane; then ONE table read, one multiply and a 16-lane sum.
+// (The histogram loop this replaces placed every grade's gain by position: ~70 dependent vector instructions, 2.3 k cycles alone and
+// 7.8 k beside another workgroup's fp32 MFMA stream, which leaves a vector instruction an issue slot only every ~32 cycles:
+// profiles/r04_fcw_stamps_fp32_prologue_detail.jsonl.)  yi: the lane's grades, 0 for padded / inactive documents.  Wave-uniform result.
+template <int W, int SLOTS>
+__device__ __forceinline__ void grade_counts(const int (&yi)[SLOTS], int &cl) {      // lane w - 1 of cl <- c_w, w = W .. 15, until c_w = 0
+    if constexpr (W <= 15) {
+        int c = 0;
+#pragma unroll
+        for (int sl = 0; sl < SLOTS; ++sl) c += __popcll(__ballot(yi[sl] >= W));
+        if (c == 0) return;                         // no label reaches W: none reaches W + 1 either
+        asm("v_writelane_b32 %0, %1, %2" : "+v"(cl) : "s"(c), "n"(W - 1));      // (one SGPR per VOP3 on gfx9: the lane is an immediate)
+        grade_counts<W + 1, SLOTS>(yi, cl);
+    }
+}
+template <int SLOTS>
+__device__ __forceinline__ float ideal_dcg_by_counts(const int (&yi)[SLOTS], const float *dcum, int lane) {
+    int cl = 0;
+    grade_counts<1, SLOTS>(yi, cl);
+    float v = cl > 0 ? dcum[cl - 1] * __builtin_ldexpf(1.f, lane) : 0.f;         // lanes >= 15 hold 0
+    v += LTR_DPP(v, LTR_DPP_XOR1);
+    v += LTR_DPP(v, LTR_DPP_XOR2);
+    v += LTR_DPP(v, LTR_DPP_HALF_MIRROR);
+    v += LTR_DPP(v, LTR_DPP_MIRROR);
+    return lane_bcast(v, 0);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -399,7 +436,6 @@ __device__ __forceinline__ float approx_ndcg_fused(int t, Score score, float *sc
     float sv[SLOTS], yc[SLOTS];
     bool real[SLOTS];
     bool bad = false, noultra = false;
-    float ymax = 0.f;
 #pragma unroll
     for (int sl = 0; sl < SLOTS; ++sl) {
         const int j = lane + 64 * sl;
@@ -408,6 +444,7 @@ __device__ __forceinline__ float approx_ndcg_fused(int t, Score score, float *sc
         real[sl] = act && gn[act ? j : 0] >= 0.f;
         yc[sl] = act ? fmaxf(yl[act ? j : 0], 0.f) : 0.f;
     }
+    stamp(15);
     const float sref = alpha * lane_bcast(sv[0], 0);
 #pragma unroll
     for (int sl = 0; sl < SLOTS; ++sl) {
@@ -419,7 +456,6 @@ __device__ __forceinline__ float approx_ndcg_fused(int t, Score score, float *sc
         const float u = real[sl] ? expf(x) : 1.f;
         const bool isint = yc[sl] <= 15.f && yc[sl] == floorf(yc[sl]);
         noultra = noultra || (real[sl] && !isint);
-        ymax = fmaxf(ymax, (real[sl] && isint) ? yc[sl] : 0.f);
         if (act) {
             uu[j] = u;
             um[j] = real[sl] ? u : 0.f;
@@ -427,6 +463,7 @@ __device__ __forceinline__ float approx_ndcg_fused(int t, Score score, float *sc
             if (WRITE_SC) sc[j] = sv[sl];
         }
     }
+    stamp(11);
     const bool fast = __ballot(bad) == 0ull;
     const bool ultra = ultra_ok && fast && __ballot(noultra) == 0ull;
     const float *ub = uu + 4 * cg, *nb = um + 4 * cg, *mb = mk + 4 * cg, *gb = gg + 4 * cg;
@@ -440,33 +477,14 @@ __device__ __forceinline__ float approx_ndcg_fused(int t, Score score, float *sc
 
     // ================= no-clamp path: integer grades, |alpha (s_k - s_0)| <= 8 =================
     auto ultra_first = [&]() {
-        // ideal DCG from the label histogram: the document at sorted position r has the grade v with
-        // (#labels > v) <= r < (#labels >= v); grade 0 carries no gain.  Counts by ballot: wave-uniform, no LDS.
+        // ideal DCG from per-grade counts (ideal_dcg_by_counts): wave-uniform, one LDS read
         {
-            const int ytop = __builtin_amdgcn_readfirstlane((int)wave_allmax(ymax));
-            float gr[SLOTS];
+            int yi[SLOTS];
 #pragma unroll
-            for (int sl = 0; sl < SLOTS; ++sl) gr[sl] = 0.f;
-            int cum = 0;
-            for (int v = ytop; v >= 1; --v) {
-                int c = 0;
-#pragma unroll
-                for (int sl = 0; sl < SLOTS; ++sl) c += __popcll(__ballot(real[sl] && yc[sl] == (float)v));
-                const float gain = (float)((1 << v) - 1);
-#pragma unroll
-                for (int sl = 0; sl < SLOTS; ++sl) {
-                    const int r = lane + 64 * sl;
-                    gr[sl] = (r >= cum && r < cum + c) ? gain : gr[sl];
-                }
-                cum += c;
-            }
-            float acc = 0.f;
-#pragma unroll
-            for (int sl = 0; sl < SLOTS; ++sl) acc = fmaf(gr[sl], invd[(lane + 64 * sl) & (S - 1)], acc);      // 1 / log2(2 + rank): LDS table
-            idcg_u = wave_allsum(acc);
+            for (int sl = 0; sl < SLOTS; ++sl) yi[sl] = real[sl] ? (int)yc[sl] : 0;
+            idcg_u = ideal_dcg_by_counts<SLOTS>(yi, invd + 128, lane);
         }
         stamp(10);
-        stamp(11);
         // ---- sweep 1: pos_i - 1 = sum_j um_j / (u_i + u_j) - 1/2 [i real]
         // The pair reciprocals r_ij = 1 / (u_i + u_j) of this lane's 4 QPL columns STAY IN REGISTERS from sweep 1 to sweep 2
         // (64 VGPRs at two lanes per row, 32 at four): sweep 1 is add + v_rcp_f32 + fma per pair, sweep 2 one multiply and two fma
@@ -688,7 +706,6 @@ __device__ __forceinline__ float approx_ndcg_fused_shared(int t, Score score, fl
     float sv[SLOTS], yc[SLOTS];
     bool real[SLOTS];
     bool bad = false, noultra = false;
-    float ymax = 0.f;
 #pragma unroll
     for (int sl = 0; sl < SLOTS; ++sl) {
         const int j = lane + 64 * sl;
@@ -708,7 +725,6 @@ __device__ __forceinline__ float approx_ndcg_fused_shared(int t, Score score, fl
         const float u = real[sl] ? expf(x) : 1.f;
         const bool isint = yc[sl] <= 15.f && yc[sl] == floorf(yc[sl]);
         noultra = noultra || (real[sl] && !isint);
-        ymax = fmaxf(ymax, (real[sl] && isint) ? yc[sl] : 0.f);
         if (act) {
             uu[j] = u;
             um[j] = real[sl] ? u : 0.f;
@@ -720,28 +736,11 @@ __device__ __forceinline__ float approx_ndcg_fused_shared(int t, Score score, fl
     const bool ultra = ultra_ok && fast && __ballot(noultra) == 0ull;
     float idcg_own = 0.f;
     if (ultra) {
-        // ideal DCG from the label histogram (see approx_ndcg_fused): counts by ballot, wave-uniform, no LDS
-        const int ytop = __builtin_amdgcn_readfirstlane((int)wave_allmax(ymax));
-        float gr[SLOTS];
+        // ideal DCG from per-grade counts (ideal_dcg_by_counts): wave-uniform, one LDS read
+        int yi[SLOTS];
 #pragma unroll
-        for (int sl = 0; sl < SLOTS; ++sl) gr[sl] = 0.f;
-        int cum = 0;
-        for (int v = ytop; v >= 1; --v) {
-            int c = 0;
-#pragma unroll
-            for (int sl = 0; sl < SLOTS; ++sl) c += __popcll(__ballot(real[sl] && yc[sl] == (float)v));
-            const float gain = (float)((1 << v) - 1);
-#pragma unroll
-            for (int sl = 0; sl < SLOTS; ++sl) {
-                const int r = lane + 64 * sl;
-                gr[sl] = (r >= cum && r < cum + c) ? gain : gr[sl];
-            }
-            cum += c;
-        }
-        float acc = 0.f;
-#pragma unroll
-        for (int sl = 0; sl < SLOTS; ++sl) acc = fmaf(gr[sl], invd[(lane + 64 * sl) & (S - 1)], acc);      // 1 / log2(2 + rank): LDS table
-        idcg_own = wave_allsum(acc);
+        for (int sl = 0; sl < SLOTS; ++sl) yi[sl] = real[sl] ? (int)yc[sl] : 0;
+        idcg_own = ideal_dcg_by_counts<SLOTS>(yi, invd + 128, lane);
     }
     stamp(10);
     stamp(11);

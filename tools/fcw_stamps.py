@@ -33,8 +33,9 @@ for per_cu in (1, 2):
     t = stamps[:, :4].cpu().double()
     d = (t[:, :, 1:10] - t[:, :, 0:9]).reshape(-1, 9).median(0).values
     tot = float((t[:, :, 9] - t[:, :, 0]).reshape(-1).median())
-    lo = t[:, :, [6, 10, 11, 12, 13, 14, 7]]
-    ld = (lo[:, :, 1:] - lo[:, :, :-1]).reshape(-1, 6).median(0).values
-    loss_names = ["init u / mask / histogram + barrier", "flags combine", "rank+pos sweep + row epilogue", "sums (barrier)", "grad sweep", "exit barrier"]
+    lo = t[:, :, [6, 15, 11, 10, 12, 13, 14, 7]]
+    ld = (lo[:, :, 1:] - lo[:, :, :-1]).reshape(-1, 7).median(0).values
+    loss_names = ["score / label reads", "exponentials + u / mask writes", "path flags + label histogram + ideal DCG", "rank+pos sweep + row epilogue", "sums (barrier)",
+                  "grad sweep", "exit barrier"]
     print(json.dumps({"loss_detail": {n: round(float(v)) for n, v in zip(loss_names, ld)}}))
     print(json.dumps({"workgroups_per_cu": per_cu, "total_cycles_per_tile_per_workgroup": tot, "phases": {n: round(float(v)) for n, v in zip(NAMES, d)}}), flush=True)
