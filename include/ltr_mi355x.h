@@ -140,6 +140,11 @@ int ltr_trisk_fwd_bwd(const float *model, const float *baseline, int Q, float al
 int ltr_risk_tail_fwd_bwd(const float *mat, int Q, int n_systems, float alpha, int kind, int strategy, int flip, float factor,
                           int zquirk, float *value, float *dmat, void *stream);
 
+/* The tail of a tRisk loss in one launch (riskLosses.py:269-291, :332-345): mat [Q][2] = (model, baseline) per query; optional flip
+ * mat' = -mat + max(mat) (transformation 1); value [1] = factor * mean(delta) / std(delta) as ltr_trisk_fwd_bwd; dmat [Q][2] (NULL = not
+ * wanted) = d value / d mat. */
+int ltr_trisk_tail_fwd_bwd(const float *mat, int Q, float alpha, int flip, float factor, float *value, float *dmat, void *stream);
+
 /* The [queries x systems] effectiveness matrix of the six risk-sensitive losses in ONE launch (losses/riskLosses/riskLosses.py:8-49,
  * :63-117, :128-169, :183-236, :247-276, :294-330), mat [B][1 + n_rest + (ideal != 0)] row-major: column 0 the model, then the
  * baseline rankers, optionally the ideal ranking (the reference vector itself); and jac [B][S] = d mat[b][0] / d x0[b][j] (NULL = not

@@ -134,6 +134,55 @@ trisk_kernel(const float *__restrict__ a, const float *__restrict__ b, int Q, fl
     }
 }
 
+// The TAIL of a tRisk loss in one launch (riskLosses.py:269-291 / :332-345) on the [Q][2] matrix (model, baseline): the flip of
+// transformation 1 (mat' = -mat + max(mat), in the reference's fp32 arithmetic), the alpha-weighted deltas, mean / std, the
+// `negative` factor; value and d value / d mat together.  The flip's whole-matrix maximum gets no gradient: the gradients of the
+// two columns of a query are g and -g, so their sum over the matrix is zero.
+__global__ void __launch_bounds__(kRiskThreads)
+trisk_tail_kernel(const float *__restrict__ mat, int Q, float alpha, int flip, float factor, float *__restrict__ value,
+                  float *__restrict__ dmat) {
+    __shared__ double red[kRiskThreads / LTR_WAVE];
+    const int tid = threadIdx.x;
+    float M = 0.f;
+    if (flip) {
+        float mx = -INFINITY;
+        for (int e = tid; e < 2 * Q; e += kRiskThreads) mx = fmaxf(mx, mat[e]);
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, LTR_WAVE));
+        __syncthreads();
+        if ((tid & (LTR_WAVE - 1)) == 0) red[tid / LTR_WAVE] = (double)mx;
+        __syncthreads();
+        M = (float)red[0];
+        for (int w = 1; w < kRiskThreads / LTR_WAVE; ++w) M = fmaxf(M, (float)red[w]);
+        __syncthreads();
+    }
+    auto at = [&](int q, int j) -> float { return flip ? -mat[2 * (size_t)q + j] + M : mat[2 * (size_t)q + j]; };
+    double s = 0.0;
+    for (int q = tid; q < Q; q += kRiskThreads) {
+        const float a = at(q, 0), b = at(q, 1);
+        s += ((double)a - (double)b) * (a < b ? 1.0 + (double)alpha : 1.0);
+    }
+    const double mu = block_sum_f64(s, red) / (double)Q;
+    double v = 0.0;
+    for (int q = tid; q < Q; q += kRiskThreads) {
+        const float a = at(q, 0), b = at(q, 1);
+        const double x = ((double)a - (double)b) * (a < b ? 1.0 + (double)alpha : 1.0);
+        v += (x - mu) * (x - mu);
+    }
+    const double var = block_sum_f64(v, red) / (double)(Q - 1);
+    const double se = sqrt(var);
+    if (tid == 0) value[0] = (float)(mu / se) * factor;
+    if (!dmat) return;
+    for (int q = tid; q < Q; q += kRiskThreads) {
+        const float a = at(q, 0), b = at(q, 1);
+        const double c = a < b ? 1.0 + (double)alpha : 1.0;
+        const double x = ((double)a - (double)b) * c;
+        const float g = (float)((1.0 / ((double)Q * se) - mu * (x - mu) / ((double)(Q - 1) * se * var)) * c) * factor;
+        dmat[2 * (size_t)q] = flip ? -g : g;
+        dmat[2 * (size_t)q + 1] = flip ? g : -g;
+    }
+}
+
 inline int status() {
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? LTR_OK : (int)e;
@@ -409,6 +458,14 @@ int ltr_trisk_fwd_bwd(const float *model, const float *baseline, int Q, float al
     if (Q < 1) return LTR_ERR_SHAPE;
     hipLaunchKernelGGL(trisk_kernel, dim3(1), dim3(kRiskThreads), 0, (hipStream_t)stream, model, baseline, Q, alpha, value,
                        dmodel, dbaseline);
+    return status();
+}
+
+int ltr_trisk_tail_fwd_bwd(const float *mat, int Q, float alpha, int flip, float factor, float *value, float *dmat, void *stream) {
+    if (!mat || !value) return LTR_ERR_NULL;
+    if (Q < 1 || Q > (1 << 29)) return LTR_ERR_SHAPE;
+    hipLaunchKernelGGL(trisk_tail_kernel, dim3(1), dim3(kRiskThreads), 0, (hipStream_t)stream, mat, Q, alpha, flip ? 1 : 0, factor, value,
+                       dmat);
     return status();
 }
 

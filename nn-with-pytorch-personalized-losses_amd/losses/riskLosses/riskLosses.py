@@ -285,7 +285,9 @@ def _regular_pair(y_predicted, y_true, y_baseline):
 
 
 def _trisk_pair_tail(mat, lt, alpha, negative):
-    """[B, 2] (model, baseline) -> flip (transformation 1 only, :269-271) -> tRisk."""
+    """[B, 2] (model, baseline) -> flip (transformation 1 only, :269-271) -> tRisk: one launch for a regular fp32 matrix."""
+    if mat.dim() == 2 and mat.shape[1] == 2 and mat.shape[0] > 1 and mat.dtype == torch.float32 and not isinstance(negative, torch.Tensor):
+        return _risk.trisk_tail(mat, alpha, lt == 1, float(negative))
     if lt == 1:
         mat = -mat + torch.max(mat)
     return _factor(negative, mat) * _risk.TRisk.apply(mat[:, 0], mat[:, 1], alpha)
@@ -314,6 +316,14 @@ def tRiskListnetLoss(y_predicted, y_true, y_baselines, alpha=5, listnet_transfor
 
 def tRiskLambdaLoss(y_predicted, y_true, y_baselines, alpha=5, listnet_transformation=1, negative=1,
                     weighing_scheme="ndcgLoss2PP_scheme"):
+    reg = _regular_pair(y_predicted, y_true, y_baselines)
+    if reg is not None and listnet_transformation in (1, 2, 3) and 1 < reg[0].shape[1] <= _FUSED_MAX_SLATE:
+        # three launches: column sums of model / baseline / ideal with the slate softmaxes inside, the [B, 2] matrix, flip + tRisk
+        require_device(y_predicted, y_true)
+        yp, yt, yb = reg
+        cs3 = _risk.lambda_colsum_systems(yp, yt, yb.unsqueeze(2).contiguous(), weighing_scheme)
+        mat = _risk.risk_matrix(cs3[2], cs3[0], cs3[1:2], 1, listnet_transformation, False)
+        return _trisk_pair_tail(mat, listnet_transformation, alpha, negative)
     p_true, p_pred, p_base = _probs(y_predicted, y_true, y_baselines)
     cs = lambda p: _risk.lambda_colsum(p, p_true, weighing_scheme)                          # noqa: E731
     q_true, q_pred, q_base = cs(p_true), cs(p_pred), cs(p_base)

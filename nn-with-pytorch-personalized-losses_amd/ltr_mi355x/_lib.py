@@ -40,6 +40,7 @@ _PROTOTYPES = {
     "ltr_lambda_colsum_sys_bwd": (c_int, [P, P, c_int, c_int, c_int, c_int, c_float, c_float, c_float, c_float, c_int, P, P, P]),
     "ltr_risk_fwd_bwd": (c_int, [P, c_int, c_int, c_int, c_float, c_int, P, P, P]),
     "ltr_trisk_fwd_bwd": (c_int, [P, P, c_int, c_float, P, P, P, P]),
+    "ltr_trisk_tail_fwd_bwd": (c_int, [P, c_int, c_float, c_int, c_float, P, P, P]),
     "ltr_risk_tail_fwd_bwd": (c_int, [P, c_int, c_int, c_float, c_int, c_int, c_int, c_float, c_int, P, P, P]),
     "ltr_risk_matrix_fwd": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P, P, P]),
     "ltr_ndcg_at_k": (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, c_int, P, P, P]),

@@ -238,6 +238,32 @@ class RiskTail(torch.autograd.Function):
         return (dmat * go.to(torch.float32),) + (None,) * 6
 
 
+class TRiskTail(torch.autograd.Function):
+    """Flip + alpha-weighted deltas + mean / std + `negative` factor of a tRisk loss on its [queries, 2] matrix in one launch
+    (riskLosses.py:269-291, :332-345) -> ltr_trisk_tail_fwd_bwd."""
+
+    @staticmethod
+    def forward(ctx, mat, alpha, flip, factor):
+        with torch.cuda.device(mat.device):
+            m = _f32(mat)
+            out = torch.empty(1, dtype=torch.float32, device=mat.device)
+            dmat = torch.empty_like(m) if ctx.needs_input_grad[0] else None
+            check(lib().ltr_trisk_tail_fwd_bwd(_ptr(m), m.shape[0], float(alpha), int(bool(flip)), float(factor), _ptr(out), _ptr(dmat),
+                                               _stream()), "ltr_trisk_tail_fwd_bwd")
+        ctx.save_for_backward(dmat)
+        return out
+
+    @staticmethod
+    def backward(ctx, go):
+        (dmat,) = ctx.saved_tensors
+        return (dmat * go.to(torch.float32),) + (None,) * 3
+
+
+def trisk_tail(mat, alpha, flip, factor):
+    require_device(mat)
+    return TRiskTail.apply(mat, alpha, flip, factor)
+
+
 def risk_tail(mat, alpha, kind, strategy, flip, factor, zquirk=False):
     require_device(mat)
     return RiskTail.apply(mat, alpha, kind, strategy, flip, factor, zquirk)

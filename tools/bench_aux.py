@@ -89,6 +89,19 @@ def main():
         rec["device_kernels_per_step"] = prof_launches
         print(json.dumps(rec), flush=True)
 
+        # tRisk (one baseline): Listnet flavour = matrix launch + tail launch; Lambda flavour = softmaxes + column sums + matrix + tail
+        yb1 = ybd[:, :, 0].contiguous()
+        for name, fn in (("tRiskListnetLoss", lambda a_, b_, c_: RL.tRiskListnetLoss(a_, b_, c_, listnet_transformation=1)),
+                         ("tRiskLambdaLoss", lambda a_, b_, c_: RL.tRiskLambdaLoss(a_, b_, c_, listnet_transformation=1))):
+            def dev_step_t():
+                ypd.grad = None
+                fn(ypd, ytd, yb1).sum().backward()
+            rec = {"row": "f-1", "what": f"{name} fwd+bwd, B={B}, S={S}, 1 baseline, transformation 1 (flip + tRisk tail in one launch)",
+                   "gpu_ms": round(gpu_ms(dev_step_t), 3)}
+            graphed = GraphedLoss(fn, (ypd.detach(), ytd, yb1))
+            rec["gpu_ms_hipgraph"] = round(gpu_ms(lambda: graphed(ypd.detach(), ytd, yb1)), 3)
+            print(json.dumps(rec), flush=True)
+
     # ---- f-4: NDCG@10 per query (the reference loops over queries in Python after every epoch) and GeoRisk of 4 systems
     Q, S = 100_000, 128
     y = torch.randint(0, 5, (Q, S), device=dev).float()
