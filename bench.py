@@ -143,6 +143,7 @@ def secondary_lines(a):
     """Second lines measured by CHILD processes with the same shapes (never exec from this GPU-touched process):
       f16x2  : the f16 x 2 split-precision variant of the pipeline (same C ABI, LTR_LIB; parity-green at the fp32 bars) on the
                headline workload -- reported next to the exact-fp32 headline, not instead of it;
+      triple : TripleLayerNet (136-64-32-1, tripleLayer.py:5-17) on the headline workload: its fused step runs folded (HBM-bound);
       two64  : the 136-64-1 two-layer scorer BASELINE.json configs[0] names, the configuration the 60 % HBM target was
                written for (exact-fp32 library); two64_f16x2: the same on the split-precision variant;
       config5: BASELINE.json configs[4] -- architeture/transformer.py scorer (make_model: FC 136->128, 6 encoder blocks,
@@ -153,6 +154,7 @@ def secondary_lines(a):
     base = [sys.executable, here, "--steps", str(a.steps), "--warmup", str(a.warmup), "--queries", str(a.queries), "--slate",
             str(a.slate), "--batch", str(a.batch), "--no-cpu-baseline", "--no-extras"]
     runs = {"f16x2": (base + ["--net", "double"], {"LTR_LIB": variant} if os.path.exists(variant) else None),
+            "triple": (base + ["--net", "triple"], {}),
             "two64": (base + ["--net", "two64"], {}),
             "two64_f16x2": (base + ["--net", "two64"], {"LTR_LIB": variant} if os.path.exists(variant) else None)}
     out = {}
@@ -165,7 +167,8 @@ def secondary_lines(a):
             line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
             j = json.loads(line)
             out[name] = {"value": j["value"], "unit": j["unit"], "ms_per_step": j["ms_per_step"], "workload": j["config"]["workload"],
-                         "roofline": {k: j["roofline"][k] for k in ("achieved", "frac", "kernel_ms", "hbm_achieved_GBps", "hbm_frac_of_8TBps")}}
+                         "roofline": {k: j["roofline"][k] for k in ("bound", "achieved", "frac", "unit", "kernel_ms", "hbm_achieved_GBps", "hbm_frac_of_8TBps",
+                                                                    "mfma_frac_of_layerwise_flops", "mfma_frac_of_executed_flops") if k in j["roofline"]}}
             if j["roofline"].get("traffic") is not None:
                 out[name]["roofline"]["traffic"] = j["roofline"]["traffic"]
             if name in ("f16x2", "two64_f16x2"):
@@ -326,6 +329,17 @@ def main():
                          "hbm_achieved_GBps": round(ach_gb, 1), "hbm_frac_of_8TBps": round(ach_gb / PEAK_HBM_GBPS, 4),
                          "hbm_frac_of_measured_copy": round(ach_gb / PEAK_HBM_MEASURED_GBPS, 4)},
         }
+        if a.net == "triple" and one_launch and getattr(ranker, "fold", None) is not None:
+            # TripleLayerNet runs FOLDED (l2 . l1 as one 136 -> 32 layer, tripleLayer.py:14-16 has no activation between them): the
+            # kernel executes 2.46 x fewer multiply-adds than the layer-by-layer formulation, so the fp32-MFMA fraction of the
+            # REFERENCE's flops can exceed 1 -- the bound that is left is HBM (X read once)
+            exec_fl = 2.0 * ((136 * 32 + 32) + (136 * 32 + 32)) * S
+            r = out["roofline"]
+            r.update({"bound": "hbm", "achieved": r["hbm_achieved_GBps"], "peak": PEAK_HBM_GBPS, "unit": "GB/s", "frac": r["hbm_frac_of_8TBps"],
+                      "kernel": "fcw_fused_kernel<TripleFolded> (csrc/ltr_fcw.h, two document-split copies of the 32 folded units)",
+                      "mfma_frac_of_layerwise_flops": round(ach_tf / PEAK_F32_MFMA_TFLOPS, 4), "executed_flops_per_slate": exec_fl,
+                      "mfma_frac_of_executed_flops": round(exec_fl * B / (kern_ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4)})
+            out["config"]["workload"] = out["config"]["workload"].replace("(136-64-32-1)", "(136-64-32-1, l2.l1 folded to 136-32-1 inside the step)")
         out["per_rank"] = [{"rank": r, "ms_per_step_local": round(float(t[0]), 4), "kernel_ms": round(float(t[1]), 4),
                             "allreduce_ms": round(float(t[2]), 4)} for r, t in enumerate(per_rank)]
         if world == 1 and not a.no_cpu_baseline:

@@ -89,6 +89,10 @@ __global__ void __launch_bounds__(kFcwThreads, 2) fcw_fused_kernel(const PipeArg
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int q = lane >> 4, d = lane & 15;
     const int n_mine = 16 * w + d;                   // this lane's hidden unit (accumulator column)
+    // document split (N::DS == 2: the hidden rows are two copies of 32 units, NetT): this wave's units see the document tiles
+    // T0 .. T0 + NTW - 1 of a super-tile only; DS == 1: all eight
+    constexpr int NTW = 8 / N::DS, WPC = kFcwWaves / N::DS;         // document tiles per wave; waves per copy
+    const int T0 = N::DS == 1 ? 0 : (w / WPC) * NTW;
 
     // ---- once per kernel: resident W1 fragments, w3, pads of the X rows, loss scratch
     const float w3n = a.packed[N::W3_OFF + n_mine];
@@ -242,10 +246,10 @@ __global__ void __launch_bounds__(kFcwThreads, 2) fcw_fused_kernel(const PipeArg
         __syncthreads();                              // C: the tile is complete in LDS
         FCW_STAMP(3)
         // ---- fc1: z1[doc][n] for my 16 hidden units, all 8 document tiles; A = image rows, B = resident fragments
-        f32x4 h1[8];
+        f32x4 h1[NTW];
 #if LTR_F16X2
         {
-            const uint16_t *rh = Xhi + d * LDH + 8 * q, *rl = Xlo + d * LDH + 8 * q;
+            const uint16_t *rh = Xhi + (16 * T0 + d) * LDH + 8 * q, *rl = Xlo + (16 * T0 + d) * LDH + 8 * q;
             u32x4 fh[2][KP], fl[2][KP];              // A fragments of two document tiles: the reads of T+1 fly under the MFMAs of T
 #pragma unroll
             for (int P = 0; P < KP; ++P) {
@@ -253,8 +257,8 @@ __global__ void __launch_bounds__(kFcwThreads, 2) fcw_fused_kernel(const PipeArg
                 fl[0][P] = *reinterpret_cast<const u32x4 *>(rl + 32 * P);
             }
 #pragma unroll
-            for (int T = 0; T < 8; ++T) {
-                if (T + 1 < 8) {
+            for (int T = 0; T < NTW; ++T) {
+                if (T + 1 < NTW) {
 #pragma unroll
                     for (int P = 0; P < KP; ++P) {
                         fh[(T + 1) & 1][P] = *reinterpret_cast<const u32x4 *>(rh + 16 * (T + 1) * LDH + 32 * P);
@@ -279,14 +283,14 @@ __global__ void __launch_bounds__(kFcwThreads, 2) fcw_fused_kernel(const PipeArg
         {
             // lane (doc, q) reads floats 16 S + 4 q .. + 3 of its document's row; in the last feature group the quads past the row
             // (their W1 fragments are zero) are taken from the row's last quad instead (finite, and the lane's own row)
-            const float *ra = Xs + d * LDX + 4 * q;
+            const float *ra = Xs + (16 * T0 + d) * LDX + 4 * q;
             const int last = 16 * (XT - 1) + (q < LASTQ ? 0 : 4 * (LASTQ - 1 - q));
             f32x4 fa[2][XT];                          // A fragments of two document tiles: the reads of T+1 fly under the MFMAs of T
 #pragma unroll
             for (int S = 0; S < XT; ++S) fa[0][S] = *reinterpret_cast<const f32x4 *>(ra + (S + 1 < XT ? 16 * S : last));
 #pragma unroll
-            for (int T = 0; T < 8; ++T) {
-                if (T + 1 < 8) {
+            for (int T = 0; T < NTW; ++T) {
+                if (T + 1 < NTW) {
 #pragma unroll
                     for (int S = 0; S < XT; ++S)
                         fa[(T + 1) & 1][S] = *reinterpret_cast<const f32x4 *>(ra + 16 * (T + 1) * LDX + (S + 1 < XT ? 16 * S : last));
@@ -316,7 +320,7 @@ __global__ void __launch_bounds__(kFcwThreads, 2) fcw_fused_kernel(const PipeArg
         long long left64 = a.n_docs - doc_base;
         const int docs_left = (int)(left64 > kTileDocs ? kTileDocs : left64);        // documents of this tile that exist (uniform)
 #pragma unroll
-        for (int T = 0; T < 8; ++T)
+        for (int T = 0; T < NTW; ++T)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 float v = h1[T][r] * un;
@@ -326,10 +330,10 @@ __global__ void __launch_bounds__(kFcwThreads, 2) fcw_fused_kernel(const PipeArg
             }
         if (drop) {      // (uniform) training-mode dropout: its own loop, so that the hash arithmetic does not sit in the common path
 #pragma unroll
-            for (int T = 0; T < 8; ++T)
+            for (int T = 0; T < NTW; ++T)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int dl = 16 * T + 4 * q + r;
+                    const int dl = 16 * (T0 + T) + 4 * q + r;
                     const long long doc = doc_base + dl;
                     bool keep;
                     if (a.keep1) keep = dl < docs_left && a.keep1[doc * N::H1 + n_mine] != 0;
@@ -339,16 +343,23 @@ __global__ void __launch_bounds__(kFcwThreads, 2) fcw_fused_kernel(const PipeArg
         }
         // score partial w3 . h1 over my 16 hidden units: sum over the 16 lanes of a DPP row, for each of my 32 documents
 #pragma unroll
-        for (int T = 0; T < 8; ++T) {
+        for (int T = 0; T < NTW; ++T) {
             f32x4 sv;
 #pragma unroll
             for (int r = 0; r < 4; ++r) sv[r] = row_sum_to_lane15(h1[T][r] * w3n);
-            if (d == 15) *reinterpret_cast<f32x4 *>(part + w * kTileDocs + 16 * T + 4 * q) = sv;
+            if (d == 15) *reinterpret_cast<f32x4 *>(part + w * kTileDocs + 16 * (T0 + T) + 4 * q) = sv;
         }
         FCW_STAMP(5)
+        // score of document j of the tile: the partials of the waves whose units saw it (all four; DS == 2: the two of its half)
+        auto doc_score = [&](int j) {
+            const float *pp = part + j;
+            if (N::DS == 1) return ((pp[0] + pp[kTileDocs]) + (pp[2 * kTileDocs] + pp[3 * kTileDocs])) + b3;
+            const float *ph = pp + (j / (kTileDocs / N::DS)) * WPC * kTileDocs;
+            return (ph[0] + ph[kTileDocs]) + b3;
+        };
         __syncthreads();                              // D: the four partials of every document are out
         if (LOSS != 0) {                              // (approxNDCG sums the partials inside its wave-private prologue: no second barrier)
-            if (tid < kTileDocs) sc[tid] = ((part[tid] + part[kTileDocs + tid]) + (part[2 * kTileDocs + tid] + part[3 * kTileDocs + tid])) + b3;
+            if (tid < kTileDocs) sc[tid] = doc_score(tid);
             __syncthreads();
         }
         FCW_STAMP(6)
@@ -367,10 +378,7 @@ __global__ void __launch_bounds__(kFcwThreads, 2) fcw_fused_kernel(const PipeArg
                 auto run = [&](auto s_tag, auto nw_tag, auto stamper) {
                     constexpr int SS = decltype(s_tag)::value, NWS = decltype(nw_tag)::value;
                     const int gi = tid / (64 * NWS), so2 = gi * SS;
-                    auto score = [&](int j) {
-                        const float *pp = part + so2 + j;
-                        return ((pp[0] + pp[kTileDocs]) + (pp[2 * kTileDocs] + pp[3 * kTileDocs])) + b3;
-                    };
+                    auto score = [&](int j) { return doc_score(so2 + j); };
                     return approx_ndcg_fused<SS, NWS, true>(tid - gi * 64 * NWS, score, sc + so2, yl + so2, gn + so2, gg + so2, uu + so2,
                                                             xt + so2, mk + so2, scratch + gi * 16, scratch + 128, a.alpha, a.eps, a.gscale,
                                                             [&](int i, float v) { dsc[so2 + i] = v; }, stamper);      // (documents past the batch carry the pad label: gradient 0)
@@ -409,8 +417,8 @@ __global__ void __launch_bounds__(kFcwThreads, 2) fcw_fused_kernel(const PipeArg
         const float sd = ldexpf(1.f, 14 - exd);
 #endif
 #pragma unroll
-        for (int T = 0; T < 8; ++T) {
-            const f32x4 ds4 = *reinterpret_cast<const f32x4 *>(dsc + 16 * T + 4 * q);
+        for (int T = 0; T < NTW; ++T) {
+            const f32x4 ds4 = *reinterpret_cast<const f32x4 *>(dsc + 16 * (T0 + T) + 4 * q);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const float ds = ds4[r];
@@ -440,9 +448,9 @@ __global__ void __launch_bounds__(kFcwThreads, 2) fcw_fused_kernel(const PipeArg
 #if LTR_F16X2
         // ---- dW1[n][f] += sum_doc dz1[doc][n] x[doc][f]: A = two accumulator tiles of dz1 (split in registers), B = x k-major
         {
-            const int lb = (4 * q + (d >> 2)) * LDH + 4 * (d & 3);
+            const int lb = (16 * T0 + 4 * q + (d >> 2)) * LDH + 4 * (d & 3);
 #pragma unroll
-            for (int Kp = 0; Kp < 4; ++Kp) {
+            for (int Kp = 0; Kp < NTW / 2; ++Kp) {
                 h16x8 ahi, alo;
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
@@ -470,8 +478,8 @@ __global__ void __launch_bounds__(kFcwThreads, 2) fcw_fused_kernel(const PipeArg
         //      past the row read the row's last float (a zero pad).
         {
             static_assert(XT == 9, "two groups of four feature tiles and the tail tile");
-            const float *rb = Xs + 4 * q * LDX + 4 * d;
-            const float *rt = Xs + 4 * q * LDX + (128 + d < LDX ? 128 + d : LDX - 1);
+            const float *rb = Xs + (16 * T0 + 4 * q) * LDX + 4 * d;
+            const float *rt = Xs + (16 * T0 + 4 * q) * LDX + (128 + d < LDX ? 128 + d : LDX - 1);
             // software pipeline over the 32 (document tile, register) steps: the B values of step s + 1 are in flight under the nine
             // MFMAs (288 cycles) of step s -- left to itself the compiler reads each value right before its MFMA
             f32x4 bq[2][2];
@@ -484,8 +492,8 @@ __global__ void __launch_bounds__(kFcwThreads, 2) fcw_fused_kernel(const PipeArg
             };
             load_b(0, bq[0], bt[0]);
 #pragma unroll
-            for (int step = 0; step < 32; ++step) {
-                if (step + 1 < 32) load_b(step + 1, bq[(step + 1) & 1], bt[(step + 1) & 1]);
+            for (int step = 0; step < 4 * NTW; ++step) {
+                if (step + 1 < 4 * NTW) load_b(step + 1, bq[(step + 1) & 1], bt[(step + 1) & 1]);
                 __builtin_amdgcn_sched_barrier(0);
                 const float av = h1[step >> 2][step & 3];
 #pragma unroll

@@ -70,10 +70,15 @@ enum { MODE_FWD = 0, MODE_BWD = 1, MODE_FUSED = 2, MODE_BWD_SAVED = 3 };   // BW
 // TWO_: a two-Linear-layer scorer  w3 . act1(W1 x + b1) + b3  (no fc2: the commented-out 136-64-1 DoubleLayerNet variant of
 // doubleLayer.py:38-51, BASELINE.json configs[0]).  Declared with H2 = H1 and A2 = A1: "h2" is then h1 itself, the
 // backward through fc3 yields dz1 directly, and the fc2 / dh1 / dW2 GEMMs are compiled out.
-template <int F_, int H1_, int H2_, int A1_, int A2_, int BH1_, int BH2_, bool TWO_ = false>
+// DS_ (two-layer nets, ltr_fcw.h): 2 = the 64 hidden units are TWO COPIES of 32 real ones, copy c working on documents
+// 64 c .. 64 c + 63 of a tile only (waves 2 c, 2 c + 1): half the matrix work per tile; the host duplicates the weight rows and adds
+// the two gradient halves (ltr_triple_fold / ltr_triple_unfold_grads).
+template <int F_, int H1_, int H2_, int A1_, int A2_, int BH1_, int BH2_, bool TWO_ = false, int DS_ = 1>
 struct NetT {
     static constexpr int F = F_, H1 = H1_, H2 = H2_, A1 = A1_, A2 = A2_;
     static constexpr bool TWO = TWO_;
+    static constexpr int DS = DS_;
+    static_assert(DS_ == 1 || (TWO_ && DS_ == 2), "document-split copies exist for the two-layer kernel only");
     static_assert(!TWO_ || (H1_ == H2_ && A1_ == A2_), "two-layer nets are declared with H2 = H1, A2 = A1");
     static constexpr int XT = (F + 1 + 15) / 16;    // x tiles incl. the ones feature at index F
     static constexpr int NT1 = (H1 + 15) / 16;      // fc1 output tiles
@@ -121,7 +126,14 @@ using TripleNet = NetT<136, 64, 32, ACT_ID, ACT_SIGMOID, 2, 2>;              // 
 using DoubleNet64 = NetT<64, 64, 64, ACT_RELU_DROP, ACT_RELU_DROP, 2, 2>;
 using TripleNet64 = NetT<64, 64, 32, ACT_ID, ACT_SIGMOID, 2, 2>;
 using TwoLayerNet64h = NetT<136, 64, 64, ACT_RELU_DROP, ACT_RELU_DROP, 2, 2, true>;   // 136 -> 64 -> 1 (bench-only)
-#define LTR_FOR_NET_EXTRA(...) case LTR_NET_TWO_LAYER_64H: { using NET = TwoLayerNet64h; __VA_ARGS__; } break;
+// TripleLayerNet FOLDED: tripleLayer.py:14-16 puts NO activation between l1 and l2, so l3(sigmoid(l2(l1 x))) is the two-layer net
+// w3 . sigmoid(Weff x + beff) + b3 with Weff = W2 W1 [32 x 136], beff = W2 b1 + b2 -- 2.46 x fewer multiply-adds per document, and
+// the gradients of W1 / b1 / W2 / b2 follow from d Weff / d beff by two tiny products per STEP (ltr_triple_unfold_grads).  Run as
+// the two-layer kernel with its 64 hidden rows = two document-split copies of the 32 units (DS = 2).
+using TripleFolded = NetT<136, 64, 64, ACT_SIGMOID, ACT_SIGMOID, 2, 2, true, 2>;
+#define LTR_FOR_NET_EXTRA(...)                                                              \
+    case LTR_NET_TWO_LAYER_64H: { using NET = TwoLayerNet64h; __VA_ARGS__; } break;         \
+    case LTR_NET_TRIPLE_FOLDED: { using NET = TripleFolded; __VA_ARGS__; } break;
 
 // run the statement(s) given after `net` with NET bound to the network type of id `net` (LTR_NET_*); unknown ids ->
 // LTR_ERR_PARAM.  Variadic: the statement may contain top-level commas (kernel launches).
@@ -1493,6 +1505,56 @@ __global__ void pack_kernel(const float *__restrict__ W1, const float *__restric
 
 // Sum the per-workgroup partials in a fixed order and scatter into the flat gradient
 // [W1 (H1 x F) | b1 (H1) | W2 (H2 x H1) | b2 (H2) | w3 (H2) | b3 (1)]  (= nn.Module parameter order).
+// ---- TripleLayerNet <-> its folded two-layer form (see TripleFolded) ------------------------------------------------------
+constexpr int kTrF = 136, kTrH1 = 64, kTrH2 = 32;
+__global__ void triple_fold_kernel(const float *__restrict__ W1, const float *__restrict__ b1, const float *__restrict__ W2,
+                                   const float *__restrict__ b2, const float *__restrict__ w3, float *__restrict__ W1e,
+                                   float *__restrict__ b1e, float *__restrict__ w3e) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;           // one thread per element of [32][136 + 1]
+    if (e >= kTrH2 * (kTrF + 1)) return;
+    const int u = e / (kTrF + 1), f = e % (kTrF + 1);
+    double acc = 0.0;
+    if (f < kTrF) {
+        for (int k = 0; k < kTrH1; ++k) acc += (double)W2[u * kTrH1 + k] * (double)W1[k * kTrF + f];
+        W1e[u * kTrF + f] = W1e[(kTrH2 + u) * kTrF + f] = (float)acc;
+    } else {
+        for (int k = 0; k < kTrH1; ++k) acc += (double)W2[u * kTrH1 + k] * (double)b1[k];
+        b1e[u] = b1e[kTrH2 + u] = (float)(acc + (double)b2[u]);
+        w3e[u] = w3e[kTrH2 + u] = w3[u];
+    }
+}
+__global__ void triple_unfold_kernel(const float *__restrict__ g2, const float *__restrict__ W1, const float *__restrict__ b1,
+                                     const float *__restrict__ W2, float *__restrict__ flat) {
+    // g2 = [dW1e 64 x 136 | db1e 64 | dw3e 64 | db3];  flat = [dW1 64 x 136 | db1 64 | dW2 32 x 64 | db2 32 | dw3 32 | db3]
+    const float *gW = g2, *gb = g2 + kTrH1 * kTrF, *gw3 = gb + kTrH1, *gb3 = gw3 + kTrH1;
+    auto G = [&](int u, int f) { return (double)gW[u * kTrF + f] + (double)gW[(kTrH2 + u) * kTrF + f]; };
+    auto Gb = [&](int u) { return (double)gb[u] + (double)gb[kTrH2 + u]; };
+    constexpr int nW1 = kTrH1 * kTrF, nb1 = kTrH1, nW2 = kTrH2 * kTrH1, nb2 = kTrH2, nw3 = kTrH2;
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    int k = e;
+    if (k < nW1) {                                   // dW1[h][f] = sum_u W2[u][h] G[u][f]
+        const int h = k / kTrF, f = k % kTrF;
+        double acc = 0.0;
+        for (int u = 0; u < kTrH2; ++u) acc += (double)W2[u * kTrH1 + h] * G(u, f);
+        flat[e] = (float)acc;
+    } else if ((k -= nW1) < nb1) {                   // db1[h] = sum_u W2[u][h] gb[u]
+        double acc = 0.0;
+        for (int u = 0; u < kTrH2; ++u) acc += (double)W2[u * kTrH1 + k] * Gb(u);
+        flat[e] = (float)acc;
+    } else if ((k -= nb1) < nW2) {                   // dW2[u][h] = sum_f G[u][f] W1[h][f] + gb[u] b1[h]
+        const int u = k / kTrH1, h = k % kTrH1;
+        double acc = Gb(u) * (double)b1[h];
+        for (int f = 0; f < kTrF; ++f) acc += G(u, f) * (double)W1[h * kTrF + f];
+        flat[e] = (float)acc;
+    } else if ((k -= nW2) < nb2) {
+        flat[e] = (float)Gb(k);
+    } else if ((k -= nb2) < nw3) {
+        flat[e] = (float)((double)gw3[k] + (double)gw3[kTrH2 + k]);
+    } else if (k - nw3 == 0) {
+        flat[e] = gb3[0];
+    }
+}
+
 template <class N>
 __global__ void reduce_grads_kernel(const float *__restrict__ partials, int nparts, float *__restrict__ flat, int Fr, int H1r, int H2r) {
     // 8 lanes per parameter: lane s sums partials s, s+8, s+16, ... (independent loads in flight), then the 8
@@ -1558,10 +1620,13 @@ int launch_pipeline(const PipeArgs &a, int grid, hipStream_t stream) {
 
 template <class N>
 int pipeline_dispatch(int mode, const PipeArgs &a, int grid, hipStream_t stream) {
+    if constexpr (N::DS != 1) {          // document-split copies exist in the fused two-layer kernel only (the generic pipeline would
+        if (mode != MODE_FUSED) return LTR_ERR_PARAM;      // run every copy on every document)
+    }
     switch (mode) {
-        case MODE_FWD: return launch_pipeline<N, MODE_FWD, 0>(a, grid, stream);
-        case MODE_BWD: return launch_pipeline<N, MODE_BWD, 0>(a, grid, stream);
-        case MODE_BWD_SAVED: return launch_pipeline<N, MODE_BWD_SAVED, 0>(a, grid, stream);
+        case MODE_FWD: if constexpr (N::DS == 1) return launch_pipeline<N, MODE_FWD, 0>(a, grid, stream); else return LTR_ERR_PARAM;
+        case MODE_BWD: if constexpr (N::DS == 1) return launch_pipeline<N, MODE_BWD, 0>(a, grid, stream); else return LTR_ERR_PARAM;
+        case MODE_BWD_SAVED: if constexpr (N::DS == 1) return launch_pipeline<N, MODE_BWD_SAVED, 0>(a, grid, stream); else return LTR_ERR_PARAM;
         default:
             if constexpr (N::TWO) {      // two-layer nets: the feature-partitioned kernel, two workgroups per CU (ltr_fcw.h)
                 switch (a.loss_kind) {
@@ -1602,8 +1667,8 @@ int ltr_net_info(int net, int32_t *info) {
 
 int ltr_fused_grid(int net, int n_cus) {
     if (n_cus < 1) return LTR_ERR_PARAM;
-    if (net < LTR_NET_DOUBLE || net > LTR_NET_TWO_LAYER_64H) return LTR_ERR_PARAM;
-    if (net == LTR_NET_TWO_LAYER_64H) return 2 * n_cus;       /* 256-thread workgroups, two per CU (ltr_fcw.h) */
+    if (net < LTR_NET_DOUBLE || net > LTR_NET_TRIPLE_FOLDED) return LTR_ERR_PARAM;
+    if (net == LTR_NET_TWO_LAYER_64H || net == LTR_NET_TRIPLE_FOLDED) return 2 * n_cus;       /* 256-thread workgroups, two per CU (ltr_fcw.h) */
     return n_cus;
 }
 
@@ -1633,7 +1698,7 @@ int ltr_dropout_keep_mask(uint64_t seed, int layer, int64_t n_docs, int H, uint8
 int ltr_mlp_pack_sub(int net, int f, int h1, int h2, const float *W1, const float *b1, const float *W2, const float *b2,
                      const float *w3, const float *b3, float *packed, void *stream) {
     if (!W1 || !b1 || !w3 || !b3 || !packed) return LTR_ERR_NULL;
-    if ((!W2 || !b2) && net != LTR_NET_TWO_LAYER_64H) return LTR_ERR_NULL;     /* two-layer nets have no fc2 */
+    if ((!W2 || !b2) && net != LTR_NET_TWO_LAYER_64H && net != LTR_NET_TRIPLE_FOLDED) return LTR_ERR_NULL;     /* two-layer nets have no fc2 */
     if (!aligned16(packed)) return LTR_ERR_ALIGN;
     LTR_FOR_NET(net, {
         if (f < 1 || f > NET::F || h1 < 1 || h1 > NET::H1 || h2 < 1 || h2 > NET::H2) return LTR_ERR_SHAPE;
@@ -1665,7 +1730,7 @@ int ltr_debug_set_stamps(void *buf, int tile) {
 static int fill_common(PipeArgs &a, int net, const float *X, int64_t n_docs, const float *packed, int dropout,
                        uint64_t seed, const uint8_t *keep1, const uint8_t *keep2) {
     if (!X || !packed) return LTR_ERR_NULL;
-    if (net < LTR_NET_DOUBLE || net > LTR_NET_TWO_LAYER_64H) return LTR_ERR_PARAM;
+    if (net < LTR_NET_DOUBLE || net > LTR_NET_TRIPLE_FOLDED) return LTR_ERR_PARAM;
     if (n_docs < 0 || n_docs > ((int64_t)1 << 37)) return LTR_ERR_SHAPE;
     if (!aligned16(X) || !aligned16(packed)) return LTR_ERR_ALIGN;
     a = PipeArgs{};
@@ -1770,6 +1835,23 @@ int ltr_mlp_reduce_grads(int net, const float *partials, int grid, float *flat_g
     int32_t info[8];
     if (int rc = ltr_net_info(net, info)) return rc;
     return ltr_mlp_reduce_grads_sub(net, info[0], info[1], info[2], partials, grid, flat_grad, stream);
+}
+
+int ltr_triple_fold(const float *W1, const float *b1, const float *W2, const float *b2, const float *w3, float *W1e, float *b1e,
+                    float *w3e, void *stream) {
+    if (!W1 || !b1 || !W2 || !b2 || !w3 || !W1e || !b1e || !w3e) return LTR_ERR_NULL;
+    const int n = kTrH2 * (kTrF + 1);
+    hipLaunchKernelGGL(triple_fold_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, W1, b1, W2, b2, w3, W1e, b1e, w3e);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? LTR_OK : (int)e;
+}
+
+int ltr_triple_unfold_grads(const float *g2, const float *W1, const float *b1, const float *W2, float *flat, void *stream) {
+    if (!g2 || !W1 || !b1 || !W2 || !flat) return LTR_ERR_NULL;
+    const int n = kTrH1 * kTrF + kTrH1 + kTrH2 * kTrH1 + kTrH2 + kTrH2 + 1;
+    hipLaunchKernelGGL(triple_unfold_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, g2, W1, b1, W2, flat);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? LTR_OK : (int)e;
 }
 
 int ltr_fused_step(int net, int loss_kind, const float *X, const float *labels, int B, int S, const float *packed,

@@ -15,7 +15,7 @@ import torch
 from ._lib import LtrError, check, lib
 from .functional import _ptr, _stream, require_device
 
-NET_DOUBLE, NET_TRIPLE, NET_DOUBLE_64, NET_TRIPLE_64, NET_TWO_LAYER_64H = 0, 1, 2, 3, 4
+NET_DOUBLE, NET_TRIPLE, NET_DOUBLE_64, NET_TRIPLE_64, NET_TWO_LAYER_64H, NET_TRIPLE_FOLDED = 0, 1, 2, 3, 4, 5
 COMPILED_FEATURES = {136: (NET_DOUBLE, NET_TRIPLE), 64: (NET_DOUBLE_64, NET_TRIPLE_64)}
 
 
@@ -287,6 +287,20 @@ class FusedRanker:
         self._bind_grads()
         self.packed = torch.empty(self.info.packed_floats, dtype=torch.float32, device=dev)
         self.partials = torch.empty(self.grid * self.info.partial_floats, dtype=torch.float32, device=dev)
+        # TripleLayerNet on the 136-feature collection: its one-launch step runs FOLDED (tripleLayer.py:14-16 has no activation
+        # between l1 and l2, so l2 . l1 is ONE 136 -> 32 layer: csrc/ltr_scorer.hip TripleFolded, 2.46 x fewer multiply-adds per
+        # document) on the two-layer kernel; ltr_triple_fold makes its weights every step, ltr_triple_unfold_grads turns its
+        # gradient into the six tensors' gradients.  LTR_TRIPLE_FOLD=0 keeps the layer-by-layer kernel (A/B, tests).
+        self.fold = None
+        import os
+        if self.info.handle == NET_TRIPLE and os.environ.get("LTR_TRIPLE_FOLD", "1") != "0":
+            fi = NetInfo.get(NET_TRIPLE_FOLDED)
+            self.fold = fi
+            self.fold_grid = int(grid) if grid else int(lib().ltr_fused_grid(fi.net, cu_count(dev)))
+            self.fold_w = [torch.empty(sh, dtype=torch.float32, device=dev) for sh in ((fi.H1, fi.F), (fi.H1,), (1, fi.H2))]
+            self.fold_packed = torch.empty(fi.packed_floats, dtype=torch.float32, device=dev)
+            self.fold_partials = torch.empty(self.fold_grid * fi.partial_floats, dtype=torch.float32, device=dev)
+            self.fold_flat = torch.empty(fi.n_params, dtype=torch.float32, device=dev)
         self._loss_out = self.flat[self.info.n_params]
         self._slate = None
         self._acts = None              # saved hidden activations of the three-launch path (grown on demand)
@@ -384,9 +398,18 @@ class FusedRanker:
             k1, k2 = _mask(keep1, B * S, info.H1, info.cH1), _mask(keep2, B * S, info.H2, info.cH2)
             if self._slate is None or self._slate.numel() < B:
                 self._slate = torch.empty(B, dtype=torch.float32, device=self.device)
-            pack_params(self.info.handle, self.params, out=self.packed)
             h = lib()
-            if not one_launch or (dropout > 1 and k1 is None):     # p != 0.5: only the forward kernels carry that stream
+            three = not one_launch or (dropout > 1 and k1 is None)     # p != 0.5: only the forward kernels carry that stream
+            fold = self.fold if (not three and k1 is None and k2 is None) else None
+            net, packed, partials, grid = self.net, self.packed, self.partials, self.grid
+            if fold is None:
+                pack_params(self.info.handle, self.params, out=self.packed)
+            else:
+                pf = _params_f32(self.params)                       # W1, b1, W2, b2, w3, b3
+                check(h.ltr_triple_fold(*[_ptr(t) for t in pf[:5]], *[_ptr(t) for t in self.fold_w], _stream()), "ltr_triple_fold")
+                pack_params(fold.handle, self.fold_w + [pf[5]], out=self.fold_packed)
+                net, packed, partials, grid = fold.net, self.fold_packed, self.fold_partials, self.fold_grid
+            if three:
                 out = self._step_three_launches(h, x2, yy, B, S, dropout, int(seed) & _MASK64, k1, k2, scale, lambda_mean,
                                                 defer_norm)
                 self._bind_grads()
@@ -397,18 +420,23 @@ class FusedRanker:
                 sid, kk, sigma, mu, eps, pad, lb = self.lambda_args
                 if lambda_mean:
                     count = torch.empty(B, dtype=torch.float32, device=self.device)
-                check(h.ltr_fused_step_lambda(self.net, _ptr(x2), _ptr(yy), B, S, _ptr(self.packed), int(dropout),
+                check(h.ltr_fused_step_lambda(net, _ptr(x2), _ptr(yy), B, S, _ptr(packed), int(dropout),
                                               int(seed) & _MASK64, _ptr(k1), _ptr(k2), sid, kk, sigma, mu, eps, pad,
-                                              lb, 1.0, _ptr(self._slate), _ptr(count), _ptr(self.partials), self.grid,
+                                              lb, 1.0, _ptr(self._slate), _ptr(count), _ptr(partials), grid,
                                               _stream()), "ltr_fused_step_lambda")
             else:
-                check(h.ltr_fused_step(self.net, self.loss_kind, _ptr(x2), _ptr(yy), B, S, _ptr(self.packed),
+                check(h.ltr_fused_step(net, self.loss_kind, _ptr(x2), _ptr(yy), B, S, _ptr(packed),
                                        int(dropout), int(seed) & _MASK64, _ptr(k1), _ptr(k2), self.alpha, self.eps,
-                                       self.pad, int(self.apply_sigmoid), scale, _ptr(self._slate), _ptr(self.partials),
-                                       self.grid, _stream()), "ltr_fused_step")
+                                       self.pad, int(self.apply_sigmoid), scale, _ptr(self._slate), _ptr(partials),
+                                       grid, _stream()), "ltr_fused_step")
             if self.kernel_events is not None:
                 self.kernel_events[1].record()
-            reduce_grads(self.info, self.partials, self.grid, self.flat_grad)
+            if fold is None:
+                reduce_grads(self.info, self.partials, self.grid, self.flat_grad)
+            else:
+                reduce_grads(fold, self.fold_partials, self.fold_grid, self.fold_flat)
+                check(h.ltr_triple_unfold_grads(_ptr(self.fold_flat), _ptr(pf[0]), _ptr(pf[1]), _ptr(pf[2]), _ptr(self.flat_grad),
+                                                _stream()), "ltr_triple_unfold_grads")
             check(h.ltr_reduce_sum_f32(_ptr(self._slate), B, scale, self.flat.data_ptr() + 4 * self.info.n_params,
                                        _stream()), "ltr_reduce_sum_f32")
             if lambda_mean:
