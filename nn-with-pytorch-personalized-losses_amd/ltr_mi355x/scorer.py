@@ -15,7 +15,7 @@ import torch
 from ._lib import LtrError, check, lib
 from .functional import _ptr, _stream, require_device
 
-NET_DOUBLE, NET_TRIPLE, NET_DOUBLE_64, NET_TRIPLE_64, NET_TWO_LAYER_64H, NET_TRIPLE_FOLDED = 0, 1, 2, 3, 4, 5
+NET_DOUBLE, NET_TRIPLE, NET_DOUBLE_64, NET_TRIPLE_64, NET_TWO_LAYER_64H, NET_TRIPLE_FOLDED, NET_TRIPLE_FOLDED_32 = 0, 1, 2, 3, 4, 5, 6
 COMPILED_FEATURES = {136: (NET_DOUBLE, NET_TRIPLE), 64: (NET_DOUBLE_64, NET_TRIPLE_64)}
 
 
@@ -109,6 +109,30 @@ def pack_params(net, params, out=None):
     return out
 
 
+def triple_folds(handle):
+    """TripleLayerNet on the 136-feature collection runs FOLDED: tripleLayer.py:14-16 has no activation between l1 and l2, so
+    l2 . l1 is ONE 136 -> 32 layer (csrc/ltr_scorer.hip TripleFolded / TripleFolded32: 2.46 x fewer multiply-adds per document).
+    ltr_triple_fold makes the folded weights from the six tensors every step, ltr_triple_unfold_grads turns the folded
+    gradient into theirs.  LTR_TRIPLE_FOLD=0 keeps the layer-by-layer kernels (A/B, tests)."""
+    import os
+    return handle == NET_TRIPLE and os.environ.get("LTR_TRIPLE_FOLD", "1") != "0"
+
+
+def triple_fold(pf, copies, out=None):
+    """pf = [W1, b1, W2, b2, w3, b3] fp32 -> [W1e [32 copies, 136], b1e [32 copies], w3e [1, 32 copies]] (+ b3 unchanged)."""
+    dev = pf[0].device
+    R = 32 * copies
+    if out is None:
+        out = [torch.empty(sh, dtype=torch.float32, device=dev) for sh in ((R, 136), (R,), (1, R))]
+    check(lib().ltr_triple_fold(*[_ptr(t) for t in pf[:5]], int(copies), *[_ptr(t) for t in out], _stream()), "ltr_triple_fold")
+    return out
+
+
+def triple_unfold(g2, copies, pf, flat):
+    check(lib().ltr_triple_unfold_grads(_ptr(g2), int(copies), _ptr(pf[0]), _ptr(pf[1]), _ptr(pf[2]), _ptr(flat), _stream()),
+          "ltr_triple_unfold_grads")
+
+
 def reduce_grads(info, partials, grid, flat):
     check(lib().ltr_mlp_reduce_grads_sub(info.net, info.F, info.H1, info.H2, _ptr(partials), grid, _ptr(flat), _stream()),
           "ltr_mlp_reduce_grads_sub")
@@ -144,10 +168,19 @@ class _MLPScores(torch.autograd.Function):
     def forward(ctx, x, net, dropout, seed, keep1, keep2, *params):
         info = NetInfo.get(net)
         dev = x.device
+        ctx.fold_pf = None
         with torch.cuda.device(dev):
             x2 = _docs(x, info)
             n = x2.shape[0]
-            packed = pack_params(net, params)
+            if triple_folds(net) and keep1 is None and keep2 is None:
+                # forward and backward launches of the folded 136 -> 32 -> 1 network (NET_TRIPLE_FOLDED_32); the six tensors'
+                # gradients come back through ltr_triple_unfold_grads
+                pf = _params_f32(params)
+                info = NetInfo.get(NET_TRIPLE_FOLDED_32)
+                packed = pack_params(NET_TRIPLE_FOLDED_32, triple_fold(pf, 1) + [pf[5]])
+                ctx.fold_pf = pf[:3]
+            else:
+                packed = pack_params(net, params)
             k1, k2 = _mask(keep1, n, info.H1, info.cH1), _mask(keep2, n, info.H2, info.cH2)
             scores = torch.empty(n, dtype=torch.float32, device=dev)
             grid = default_grid(dev, n, info.tile_docs)
@@ -170,7 +203,7 @@ class _MLPScores(torch.autograd.Function):
     def backward(ctx, g):
         x2, packed, k1, k2 = ctx.saved_tensors
         net, dropout, seed, grid, dtypes = ctx.meta
-        info = NetInfo.get(net)
+        info = NetInfo.get(NET_TRIPLE_FOLDED_32 if ctx.fold_pf is not None else net)
         dev = x2.device
         n = x2.shape[0]
         with torch.cuda.device(dev):
@@ -184,6 +217,11 @@ class _MLPScores(torch.autograd.Function):
                 check(lib().ltr_mlp_backward(info.net, _ptr(x2), n, _ptr(packed), dropout, seed, _ptr(k1), _ptr(k2), _ptr(gs),
                                              _ptr(partials), grid, _stream()), "ltr_mlp_backward")
             reduce_grads(info, partials, grid, flat)
+            if ctx.fold_pf is not None:
+                info = NetInfo.get(net)
+                flat6 = torch.empty(info.n_params, dtype=torch.float32, device=dev)
+                triple_unfold(flat, 1, ctx.fold_pf, flat6)
+                flat = flat6
         grads, off = [], 0
         for shape, dt in zip(info.shapes, dtypes):
             cnt = 1
@@ -287,19 +325,18 @@ class FusedRanker:
         self._bind_grads()
         self.packed = torch.empty(self.info.packed_floats, dtype=torch.float32, device=dev)
         self.partials = torch.empty(self.grid * self.info.partial_floats, dtype=torch.float32, device=dev)
-        # TripleLayerNet on the 136-feature collection: its one-launch step runs FOLDED (tripleLayer.py:14-16 has no activation
-        # between l1 and l2, so l2 . l1 is ONE 136 -> 32 layer: csrc/ltr_scorer.hip TripleFolded, 2.46 x fewer multiply-adds per
-        # document) on the two-layer kernel; ltr_triple_fold makes its weights every step, ltr_triple_unfold_grads turns its
-        # gradient into the six tensors' gradients.  LTR_TRIPLE_FOLD=0 keeps the layer-by-layer kernel (A/B, tests).
-        self.fold = None
-        import os
-        if self.info.handle == NET_TRIPLE and os.environ.get("LTR_TRIPLE_FOLD", "1") != "0":
-            fi = NetInfo.get(NET_TRIPLE_FOLDED)
-            self.fold = fi
+        # TripleLayerNet on the 136-feature collection runs FOLDED (triple_folds above): the one-launch step on the two-layer
+        # kernel with two document-split copies of the 32 units (NET_TRIPLE_FOLDED), the three-launch path on the plain
+        # 136 -> 32 -> 1 network (NET_TRIPLE_FOLDED_32)
+        self.fold = self.fold32 = None
+        if triple_folds(self.info.handle):
+            fi, fi32 = NetInfo.get(NET_TRIPLE_FOLDED), NetInfo.get(NET_TRIPLE_FOLDED_32)
+            self.fold, self.fold32 = fi, fi32
             self.fold_grid = int(grid) if grid else int(lib().ltr_fused_grid(fi.net, cu_count(dev)))
-            self.fold_w = [torch.empty(sh, dtype=torch.float32, device=dev) for sh in ((fi.H1, fi.F), (fi.H1,), (1, fi.H2))]
-            self.fold_packed = torch.empty(fi.packed_floats, dtype=torch.float32, device=dev)
-            self.fold_partials = torch.empty(self.fold_grid * fi.partial_floats, dtype=torch.float32, device=dev)
+            self.fold_w = [torch.empty(sh, dtype=torch.float32, device=dev) for sh in ((64, 136), (64,), (1, 64))]
+            self.fold_packed = torch.empty(max(fi.packed_floats, fi32.packed_floats), dtype=torch.float32, device=dev)
+            self.fold_partials = torch.empty(max(self.fold_grid * fi.partial_floats, self.grid * fi32.partial_floats), dtype=torch.float32,
+                                             device=dev)
             self.fold_flat = torch.empty(fi.n_params, dtype=torch.float32, device=dev)
         self._loss_out = self.flat[self.info.n_params]
         self._slate = None
@@ -400,18 +437,21 @@ class FusedRanker:
                 self._slate = torch.empty(B, dtype=torch.float32, device=self.device)
             h = lib()
             three = not one_launch or (dropout > 1 and k1 is None)     # p != 0.5: only the forward kernels carry that stream
-            fold = self.fold if (not three and k1 is None and k2 is None) else None
+            fold = (self.fold32 if three else self.fold) if (k1 is None and k2 is None) else None
             net, packed, partials, grid = self.net, self.packed, self.partials, self.grid
+            pf = None
             if fold is None:
                 pack_params(self.info.handle, self.params, out=self.packed)
             else:
                 pf = _params_f32(self.params)                       # W1, b1, W2, b2, w3, b3
-                check(h.ltr_triple_fold(*[_ptr(t) for t in pf[:5]], *[_ptr(t) for t in self.fold_w], _stream()), "ltr_triple_fold")
-                pack_params(fold.handle, self.fold_w + [pf[5]], out=self.fold_packed)
-                net, packed, partials, grid = fold.net, self.fold_packed, self.fold_partials, self.fold_grid
+                copies = fold.H1 // 32
+                fw = triple_fold(pf, copies, [self.fold_w[0][:fold.H1], self.fold_w[1][:fold.H1], self.fold_w[2][:, :fold.H1]])
+                packed = self.fold_packed[:fold.packed_floats]
+                pack_params(fold.handle, fw + [pf[5]], out=packed)
+                net, partials, grid = fold.net, self.fold_partials, (self.grid if three else self.fold_grid)
             if three:
                 out = self._step_three_launches(h, x2, yy, B, S, dropout, int(seed) & _MASK64, k1, k2, scale, lambda_mean,
-                                                defer_norm)
+                                                defer_norm, fold, pf, net, packed, partials)
                 self._bind_grads()
                 return out
             if self.kernel_events is not None:
@@ -431,12 +471,7 @@ class FusedRanker:
                                        grid, _stream()), "ltr_fused_step")
             if self.kernel_events is not None:
                 self.kernel_events[1].record()
-            if fold is None:
-                reduce_grads(self.info, self.partials, self.grid, self.flat_grad)
-            else:
-                reduce_grads(fold, self.fold_partials, self.fold_grid, self.fold_flat)
-                check(h.ltr_triple_unfold_grads(_ptr(self.fold_flat), _ptr(pf[0]), _ptr(pf[1]), _ptr(pf[2]), _ptr(self.flat_grad),
-                                                _stream()), "ltr_triple_unfold_grads")
+            self._reduce(fold, pf, partials, grid)
             check(h.ltr_reduce_sum_f32(_ptr(self._slate), B, scale, self.flat.data_ptr() + 4 * self.info.n_params,
                                        _stream()), "ltr_reduce_sum_f32")
             if lambda_mean:
@@ -448,7 +483,17 @@ class FusedRanker:
         self._bind_grads()
         return self._loss_out
 
-    def _step_three_launches(self, h, x2, yy, B, S, dropout, seed, k1, k2, scale, lambda_mean, defer_norm=False):
+    def _reduce(self, fold, pf, partials, grid):
+        """Per-workgroup partials -> the flat gradient of the module's own tensors (through the unfold for a folded TripleLayerNet)."""
+        if fold is None:
+            reduce_grads(self.info, partials, grid, self.flat_grad)
+        else:
+            g2 = self.fold_flat[:fold.n_params]
+            reduce_grads(fold, partials, grid, g2)
+            triple_unfold(g2, fold.H1 // 32, pf, self.flat_grad)
+
+    def _step_three_launches(self, h, x2, yy, B, S, dropout, seed, k1, k2, scale, lambda_mean, defer_norm=False, fold=None, pf=None,
+                             net=None, packed=None, partials=None):
         """Any slate length (and lambdaLoss "mean"): scorer forward launch (writes the scores AND the post-activation
         hidden layers, 1 152 B per document for the 136-wide net) -> loss kernel (forward + dL/dscores) -> scorer backward
         launch that reads h1 / h2 back instead of recomputing fc1 / fc2: ONE forward, like the reference's autograd
@@ -456,12 +501,14 @@ class FusedRanker:
         rides on HBM bandwidth it leaves idle."""
         n = B * S
         dev = self.device
+        if net is None:
+            net, packed, partials = self.net, self.packed, self.partials
         scores = torch.empty(n, dtype=torch.float32, device=dev)
         ds = torch.empty(n, dtype=torch.float32, device=dev)
-        n_acts = int(h.ltr_mlp_acts_floats(self.net, n))
+        n_acts = int(h.ltr_mlp_acts_floats(net, n))
         if self._acts is None or self._acts.numel() < n_acts:
             self._acts = torch.empty(n_acts, dtype=torch.float32, device=dev)
-        check(h.ltr_mlp_forward_save(self.net, _ptr(x2), n, _ptr(self.packed), int(dropout), seed, _ptr(k1), _ptr(k2),
+        check(h.ltr_mlp_forward_save(net, _ptr(x2), n, _ptr(packed), int(dropout), seed, _ptr(k1), _ptr(k2),
                                      _ptr(scores), _ptr(self._acts), self.grid, _stream()), "ltr_mlp_forward_save")
         if self.loss_kind == LOSS_APPROXNDCG:
             check(h.ltr_approxndcg_fwd_bwd(_ptr(scores), _ptr(yy), B, S, self.alpha, self.eps, self.pad, scale,
@@ -476,11 +523,11 @@ class FusedRanker:
                                        _ptr(self._slate), _ptr(count), _ptr(ds), _stream()), "ltr_lambda_fwd_bwd")
         if self.kernel_events is not None:
             self.kernel_events[0].record()
-        check(h.ltr_mlp_backward_saved(self.net, _ptr(x2), n, _ptr(self.packed), int(dropout), _ptr(self._acts), _ptr(ds),
-                                       _ptr(self.partials), self.grid, _stream()), "ltr_mlp_backward_saved")
+        check(h.ltr_mlp_backward_saved(net, _ptr(x2), n, _ptr(packed), int(dropout), _ptr(self._acts), _ptr(ds),
+                                       _ptr(partials), self.grid, _stream()), "ltr_mlp_backward_saved")
         if self.kernel_events is not None:
             self.kernel_events[1].record()
-        reduce_grads(self.info, self.partials, self.grid, self.flat_grad)
+        self._reduce(fold, pf, partials, self.grid)
         check(h.ltr_reduce_sum_f32(_ptr(self._slate), B, scale, self.flat.data_ptr() + 4 * self.info.n_params,
                                    _stream()), "ltr_reduce_sum_f32")
         if lambda_mean:

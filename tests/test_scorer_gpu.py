@@ -322,9 +322,19 @@ def test_slate512_lambda_through_modules(kind, dev):
     net, sd = _make(kind, dev, 17)
     net.eval()
     B, S = 3, 512
-    gen = torch.Generator().manual_seed(512)
-    x = torch.randn(B, S, 136, generator=gen)
-    y = torch.randint(0, 5, (B, S), generator=gen).float()
+    # lambdaLoss weights every pair by the RANKS of the predicted scores (lambdaL.py:36-60): two documents whose exact scores differ by
+    # less than fp32 resolves (seed 512 holds a pair 5.7e-8 apart at |score| ~ 0.3) rank either way in ANY fp32 implementation -- the
+    # layer-by-layer kernel happened to order them like fp64, the folded TripleLayerNet not (both within 1e-7 of the fp64 scores;
+    # tools/diag_fold_rankflip.py) -- and one swapped pair moves the gradient by 4e-5.  Take the first seed without such a tie.
+    for data_seed in range(512, 640):
+        gen = torch.Generator().manual_seed(data_seed)
+        x = torch.randn(B, S, 136, generator=gen)
+        y = torch.randint(0, 5, (B, S), generator=gen).float()
+        so = _oracle_step(kind, sd, x, y, "lambdaLoss")[2]
+        if float(np.abs(np.diff(np.sort(so, axis=1), axis=1)).min()) > 4e-7:          # 4 x the kernels' score error (~1e-7)
+            break
+    else:
+        raise AssertionError("no tie-free seed")
     loss = lambdaLoss(torch.squeeze(net(x.to(dev), None, None)), y.to(dev), weighing_scheme="ndcgLoss2PP_scheme")
     loss.backward()
     rl, rg, _ = _oracle_step(kind, sd, x, y, "lambdaLoss")

@@ -35,34 +35,39 @@ def _weights(dev, seed):
     return [t.to(dev).contiguous() for t in (W1, b1, W2, b2, w3)]
 
 
-def test_fold_kernel(dev):
-    from ltr_mi355x import lib
-    from ltr_mi355x.functional import _ptr, _stream, check
+@pytest.mark.parametrize("copies", [1, 2])
+def test_fold_kernel(dev, copies):
+    from ltr_mi355x.scorer import triple_fold
     W1, b1, W2, b2, w3 = _weights(dev, 1)
-    W1e, b1e, w3e = torch.empty(64, 136, device=dev), torch.empty(64, device=dev), torch.empty(1, 64, device=dev)
-    check(lib().ltr_triple_fold(_ptr(W1), _ptr(b1), _ptr(W2), _ptr(b2), _ptr(w3), _ptr(W1e), _ptr(b1e), _ptr(w3e), _stream()), "fold")
+    W1e, b1e, w3e = triple_fold([W1, b1, W2, b2, w3], copies)
+    assert tuple(W1e.shape) == (32 * copies, 136) and tuple(b1e.shape) == (32 * copies,) and tuple(w3e.shape) == (1, 32 * copies)
     ref_W = (W2.double() @ W1.double())
     ref_b = W2.double() @ b1.double() + b2.double()
-    for half in (0, 32):
-        assert relerr(W1e[half:half + 32].cpu().numpy(), ref_W.cpu().numpy()) < 1e-7
-        assert relerr(b1e[half:half + 32].cpu().numpy(), ref_b.cpu().numpy()) < 1e-7
-        assert torch.equal(w3e[0, half:half + 32], w3[0])
-    assert torch.equal(W1e[:32], W1e[32:]) and torch.equal(b1e[:32], b1e[32:])
-
-
-def test_unfold_kernel(dev):
+    for c in range(copies):
+        assert relerr(W1e[32 * c:32 * c + 32].cpu().numpy(), ref_W.cpu().numpy()) < 1e-7
+        assert relerr(b1e[32 * c:32 * c + 32].cpu().numpy(), ref_b.cpu().numpy()) < 1e-7
+        assert torch.equal(w3e[0, 32 * c:32 * c + 32], w3[0])
+    if copies == 2:
+        assert torch.equal(W1e[:32], W1e[32:]) and torch.equal(b1e[:32], b1e[32:])
     from ltr_mi355x import lib
-    from ltr_mi355x.functional import _ptr, _stream, check
+    from ltr_mi355x.functional import _ptr, _stream
+    assert lib().ltr_triple_fold(_ptr(W1), _ptr(b1), _ptr(W2), _ptr(b2), _ptr(w3), 3, _ptr(W1e), _ptr(b1e), _ptr(w3e), _stream()) != 0
+
+
+@pytest.mark.parametrize("copies", [1, 2])
+def test_unfold_kernel(dev, copies):
+    from ltr_mi355x.scorer import triple_unfold
     W1, b1, W2, b2, w3 = _weights(dev, 2)
     g = torch.Generator().manual_seed(3)
-    g2 = torch.randn(64 * 136 + 64 + 64 + 1, generator=g).to(dev)
+    R = 32 * copies
+    g2 = torch.randn(R * 136 + R + R + 1, generator=g).to(dev)
     flat = torch.empty(64 * 136 + 64 + 32 * 64 + 32 + 32 + 1, device=dev)
-    check(lib().ltr_triple_unfold_grads(_ptr(g2), _ptr(W1), _ptr(b1), _ptr(W2), _ptr(flat), _stream()), "unfold")
+    triple_unfold(g2, copies, [W1, b1, W2], flat)
     d = g2.double()
-    GW = d[:64 * 136].view(64, 136)
-    G = GW[:32] + GW[32:]
-    gb = d[64 * 136:64 * 136 + 32] + d[64 * 136 + 32:64 * 136 + 64]
-    gw3 = d[64 * 136 + 64:64 * 136 + 96] + d[64 * 136 + 96:64 * 136 + 128]
+    GW = d[:R * 136].view(copies, 32, 136)
+    G = GW.sum(0)
+    gb = d[R * 136:R * 136 + R].view(copies, 32).sum(0)
+    gw3 = d[R * 136 + R:R * 136 + 2 * R].view(copies, 32).sum(0)
     ref = torch.cat([(W2.double().t() @ G).reshape(-1), W2.double().t() @ gb, (G @ W1.double().t() + gb[:, None] * b1.double()[None, :]).reshape(-1),
                      gb, gw3, d[-1:]])
     assert relerr(flat.cpu().numpy(), ref.cpu().numpy()) < 1e-7
@@ -125,3 +130,51 @@ def test_folded_full_size_linearity(dev):
     g_b = r.flat_grad.double().clone()
     assert abs(l_a + l_b - l_all) / abs(l_all) < 1e-5
     assert float((g_a + g_b - g_all).abs().max() / g_all.abs().max()) < 1e-4
+
+
+@pytest.mark.parametrize("n_docs", [1, 100, 128 * 37 + 5])
+def test_module_path_folded_equals_layerwise_and_oracle(n_docs, dev, monkeypatch):
+    """`net(x, None, None)` + autograd (main_batch_execution.py:128-170): forward and backward launches of the folded network."""
+    net, sd = _make("triple", dev, 21)
+    gen = torch.Generator().manual_seed(n_docs)
+    x = torch.randn(n_docs, 136, generator=gen)
+    w = torch.randn(n_docs, 1, generator=gen)
+    xd, wd = x.to(dev), w.to(dev)
+    outs = []
+    for fold in ("1", "0"):
+        monkeypatch.setenv("LTR_TRIPLE_FOLD", fold)
+        net.zero_grad()
+        s_ = net(xd, None, None)
+        (s_ * wd).sum().backward()
+        outs.append((s_.detach().cpu().numpy(), _grads(net)))
+    p = {k: v.double().clone().requires_grad_(True) for k, v in sd.items()}
+    so = O.triple_layer_forward(x.double(), p)
+    (so * w.double()).sum().backward()
+    rg = {k: v.grad.numpy() for k, v in p.items()}
+    p32 = {k: v.float().clone().requires_grad_(True) for k, v in sd.items()}
+    (O.triple_layer_forward(x, p32) * w).sum().backward()
+    rg32 = {k: v.grad.numpy() for k, v in p32.items()}
+    for s_, g_ in outs:
+        assert relerr(s_, so.detach().numpy()) < 1e-5
+        assert_grads(g_, rg, ref32=rg32)
+    assert relerr(outs[0][0], outs[1][0]) < 2e-6
+
+
+@pytest.mark.parametrize("loss,S", [("lambdaLoss", 512), ("approxNDCG", 50), ("listnet", 200)])
+def test_three_launch_path_folded(loss, S, dev):
+    """Slates other than 32 / 64 / 128: forward(+save) + loss kernel + backward(saved) of the folded 136 -> 32 -> 1 network."""
+    from ltr_mi355x.scorer import FusedRanker
+    net, sd = _make("triple", dev, 31)
+    B = 9
+    gen = torch.Generator().manual_seed(S)
+    x = torch.randn(B, S, 136, generator=gen)
+    y = torch.randint(0, 5, (B, S), generator=gen).float()
+    y[1, S - 5:] = -1.0
+    kw = dict(weighing_scheme="ndcgLoss2PP_scheme") if loss == "lambdaLoss" else {}
+    r = FusedRanker(net, loss=loss, **kw)
+    assert r.fold32 is not None
+    l = float(r.step(x.to(dev), y.to(dev)))
+    rl, rg, _ = _oracle_step("triple", sd, x, y, loss)
+    _, rg32, _ = _oracle_step("triple", sd, x, y, loss, dtype=torch.float32)
+    assert abs(l - float(rl)) <= 1e-5 * max(1.0, abs(float(rl)))
+    assert_grads(_grads(net), rg, ref32=rg32)
