@@ -77,9 +77,12 @@ __device__ __forceinline__ unsigned drop_key1(unsigned long long seed, int strea
     return mix32((unsigned)(drop_seed(seed) >> 32) + 0x85EBCA6Bu * (unsigned)stream_id + 0x165667B1u);
 }
 __global__ void seed_epoch_kernel(unsigned long long v, int add) { g_drop_epoch = add ? g_drop_epoch + v : v; }
+// (32-bit integer multiplies are quarter rate: the high word of the quad counter -- zero below 2^34 elements per stream, i.e. always
+// in practice -- joins the additive key between the two multiplies as (hi << 16 | hi) instead of costing a third multiply.)
 __device__ __forceinline__ unsigned drop_word(unsigned long long seed, int stream_id, unsigned long long quad) {
-    unsigned h = (unsigned)quad ^ drop_key0(seed, stream_id) ^ (0x27D4EB2Fu * (unsigned)(quad >> 32));
-    h ^= h >> 16; h *= 0x85EBCA6Bu; h += drop_key1(seed, stream_id); h ^= h >> 13; h *= 0xC2B2AE35u; h ^= h >> 16;
+    const unsigned hi = (unsigned)(quad >> 32);
+    unsigned h = (unsigned)quad ^ drop_key0(seed, stream_id);
+    h ^= h >> 16; h *= 0x85EBCA6Bu; h += drop_key1(seed, stream_id) + ((hi << 16) | hi); h ^= h >> 13; h *= 0xC2B2AE35u; h ^= h >> 16;
     return h;
 }
 __host__ __device__ inline unsigned drop_threshold(float p) {
@@ -99,6 +102,15 @@ __device__ __forceinline__ unsigned drop_keep4(unsigned long long seed, int stre
            (drop_win(w, 3) >= thr ? 8u : 0u);
 }
 
+// The same four decisions as BOOLEANS (compare -> select, no bit packing and unpacking between producer and consumer: the packed form
+// costs ~3 more vector instructions per element in kernels that are bound by exactly those).
+struct Keep4 { bool k[4]; };
+__device__ __forceinline__ Keep4 keep_all() { return Keep4{{true, true, true, true}}; }
+__device__ __forceinline__ Keep4 drop_keep4b(unsigned long long seed, int stream_id, unsigned long long idx, unsigned thr) {
+    const unsigned w = drop_word(seed, stream_id, idx >> 2);
+    return Keep4{{drop_win(w, 0) >= thr, drop_win(w, 1) >= thr, drop_win(w, 2) >= thr, drop_win(w, 3) >= thr}};
+}
+
 // keep flags of 4 elements in ONE column over 4 consecutive rows (idx0 + r * row_stride, r = 0..3) when the four lanes of an
 // aligned lane quad hold four adjacent columns of one element quad ((idx0 & 3) == (lane & 3), row_stride a multiple of 4):
 // the word of row r is the same for the whole lane quad, so lane i evaluates row i and takes the other three with one DPP
@@ -113,6 +125,17 @@ __device__ __forceinline__ unsigned drop_keep_col4(unsigned long long seed, int 
     const unsigned w3 = (unsigned)__builtin_amdgcn_update_dpp(0, (int)mine, 0xFF, 0xF, 0xF, false);      // [3,3,3,3]
     return (drop_win(w0, i) >= thr ? 1u : 0u) | (drop_win(w1, i) >= thr ? 2u : 0u) | (drop_win(w2, i) >= thr ? 4u : 0u) |
            (drop_win(w3, i) >= thr ? 8u : 0u);
+}
+
+__device__ __forceinline__ Keep4 drop_keep_col4b(unsigned long long seed, int stream_id, unsigned long long idx0,
+                                                 unsigned long long row_stride, unsigned thr, int lane) {
+    const unsigned i = (unsigned)lane & 3u;
+    const unsigned mine = drop_word(seed, stream_id, (idx0 >> 2) + (unsigned long long)i * (row_stride >> 2));
+    const unsigned w0 = (unsigned)__builtin_amdgcn_update_dpp(0, (int)mine, 0x00, 0xF, 0xF, false);
+    const unsigned w1 = (unsigned)__builtin_amdgcn_update_dpp(0, (int)mine, 0x55, 0xF, 0xF, false);
+    const unsigned w2 = (unsigned)__builtin_amdgcn_update_dpp(0, (int)mine, 0xAA, 0xF, 0xF, false);
+    const unsigned w3 = (unsigned)__builtin_amdgcn_update_dpp(0, (int)mine, 0xFF, 0xF, 0xF, false);
+    return Keep4{{drop_win(w0, i) >= thr, drop_win(w1, i) >= thr, drop_win(w2, i) >= thr, drop_win(w3, i) >= thr}};
 }
 
 __global__ void dropout_mask_kernel(unsigned long long seed, int stream_id, long long n, unsigned thr, uint8_t *out) {
@@ -595,12 +618,12 @@ drop_cast_colsum_kernel(const float *__restrict__ dx, long long T, int N, unsign
         if (cg.active() && c < cg.cpr)
             for (long long t = r0 + cg.rl; t < r1; t += cg.rlanes) {
                 const f32x4 v = *reinterpret_cast<const f32x4 *>(dx + t * N + c * 4);
-                const unsigned keep = thr ? drop_keep4(seed, stream_id, (unsigned long long)t * N + c * 4, thr) : 15u;
+                const Keep4 keep = thr ? drop_keep4b(seed, stream_id, (unsigned long long)t * N + c * 4, thr) : keep_all();
                 float o[4];
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
                     // the GEMMs consume the ROUNDED value: sum that, so that db = colsum(dy) holds exactly
-                    o[k] = from_bf16(to_bf16((keep >> k) & 1u ? v[k] * scale : 0.f));
+                    o[k] = from_bf16(to_bf16(keep.k[k] ? v[k] * scale : 0.f));
                     acc[k] += o[k];
                 }
                 *reinterpret_cast<u32x2 *>(out + t * N + c * 4) = u32x2{pack_bf16(o[0], o[1]), pack_bf16(o[2], o[3])};
@@ -755,9 +778,9 @@ __global__ void __launch_bounds__(256, 2) gemm_bf16_kernel(ltr_gemm_desc g) {
                     v[3] = bf16_hi(gt[1]) > 0.f ? v[3] * g.gate_scale : 0.f;
                 }
                 if (thr) {
-                    const unsigned keep = drop_keep4(g.seed, g.drop_stream, (unsigned long long)m * g.N + n, thr);
+                    const Keep4 keep = drop_keep4b(g.seed, g.drop_stream, (unsigned long long)m * g.N + n, thr);
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] = (keep >> r) & 1u ? v[r] * keep_scale : 0.f;
+                    for (int r = 0; r < 4; ++r) v[r] = keep.k[r] ? v[r] * keep_scale : 0.f;
                 }
                 if (g.residual) v += *reinterpret_cast<const f32x4 *>(g.residual + m * g.ldc + n);
             }
@@ -1038,9 +1061,9 @@ __global__ void __launch_bounds__(kFfnThreads) ffn_fwd_kernel(FfnArgs a) {
 #pragma unroll
             for (int tt = 0; tt < TT; ++tt) {
                 f32x4 v = z[tt] + bias;
-                const unsigned keep = thr ? drop_keep4(a.seed, a.stream_hidden, (unsigned long long)(tok0 + 16 * tt + j) * a.dff + h0, thr) : 15u;
+                const Keep4 keep = thr ? drop_keep4b(a.seed, a.stream_hidden, (unsigned long long)(tok0 + 16 * tt + j) * a.dff + h0, thr) : keep_all();
 #pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = (keep >> r) & 1u ? fmaxf(v[r], 0.f) * ks : 0.f;
+                for (int r = 0; r < 4; ++r) v[r] = keep.k[r] ? fmaxf(v[r], 0.f) * ks : 0.f;
                 hb[ht][tt] = u32x2{pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3])};
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -1078,9 +1101,9 @@ __global__ void __launch_bounds__(kFfnThreads) ffn_fwd_kernel(FfnArgs a) {
             const int d0 = 16 * dt + 4 * q;
             f32x4 v = y[dt][tt] + *reinterpret_cast<const f32x4 *>(a.b2 + d0);
             if (thro) {
-                const unsigned keep = drop_keep4(a.seed, a.stream_out, (unsigned long long)tok * D + d0, thro);
+                const Keep4 keep = drop_keep4b(a.seed, a.stream_out, (unsigned long long)tok * D + d0, thro);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = (keep >> r) & 1u ? v[r] * ks : 0.f;
+                for (int r = 0; r < 4; ++r) v[r] = keep.k[r] ? v[r] * ks : 0.f;
             }
             v += *reinterpret_cast<const f32x4 *>(a.x1 + tok * D + d0);
             *reinterpret_cast<f32x4 *>(a.out + tok * D + d0) = v;
@@ -1294,11 +1317,11 @@ __global__ void __launch_bounds__(kFfnThreads) ffn_bwd_w_kernel(FfnArgs a) {
             }
             f32x4 h, dz;
             const long long tok0 = t * TOK + 16 * tt + 4 * q;
-            const unsigned keep4 = thr ? drop_keep_col4(a.seed, a.stream_hidden, (unsigned long long)tok0 * a.dff + hid, (unsigned long long)a.dff, thr, lane) : 15u;
+            const Keep4 keep4 = thr ? drop_keep_col4b(a.seed, a.stream_hidden, (unsigned long long)tok0 * a.dff + hid, (unsigned long long)a.dff, thr, lane) : keep_all();
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const long long tok = tok0 + r;
-                const bool keep = (keep4 >> r) & 1u;
+                const bool keep = keep4.k[r];
                 h[r] = keep && tok < a.T ? from_bf16(to_bf16(fmaxf(z[r] + b1v, 0.f) * ks)) : 0.f;
                 dz[r] = h[r] > 0.f ? from_bf16(to_bf16(dh[r] * ks)) : 0.f;
                 db1 += dz[r];
@@ -1546,9 +1569,9 @@ __global__ void __launch_bounds__(kAttThreads, (KTMAX <= 16 ? 3 : 1)) attention_
                 for (int half = 0; half < 2; ++half) {
                     f32x4 p = st[2 * u + half];
                     if (thr) {
-                        const unsigned keep = drop_keep4(a.seed, a.stream_id, attn_idx(bh, Sp, query, 32 * u + 16 * half + 4 * g), thr);
+                        const Keep4 keep = drop_keep4b(a.seed, a.stream_id, attn_idx(bh, Sp, query, 32 * u + 16 * half + 4 * g), thr);
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) p[r] = (keep >> r) & 1u ? p[r] * ks : 0.f;
+                        for (int r = 0; r < 4; ++r) p[r] = keep.k[r] ? p[r] * ks : 0.f;
                     }
                     pk[2 * half] = pack_bf16(p[0], p[1]);
                     pk[2 * half + 1] = pack_bf16(p[2], p[3]);
@@ -1639,10 +1662,10 @@ __global__ void __launch_bounds__(kAttThreads) attention_bwd_kernel(AttArgs a) {
                 for (int half = 0; half < 2; ++half) {
                     const int kt = 2 * u + half;
                     const f32x4 dp = mfma_bf16(row_frag(img1, kt, lane), dof, zero);     // dPd^T = V dO^T
-                    const unsigned keep = thr ? drop_keep4(a.seed, a.stream_id, attn_idx(bh, Sp, query, 16 * kt + 4 * g), thr) : 15u;
+                    const Keep4 keep = thr ? drop_keep4b(a.seed, a.stream_id, attn_idx(bh, Sp, query, 16 * kt + 4 * g), thr) : keep_all();
                     f32x4 ds;
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) ds[r] = st[kt][r] * (((keep >> r) & 1u ? dp[r] * ks : 0.f) - D) * scale;
+                    for (int r = 0; r < 4; ++r) ds[r] = st[kt][r] * ((keep.k[r] ? dp[r] * ks : 0.f) - D) * scale;
                     pk[2 * half] = pack_bf16(ds[0], ds[1]);
                     pk[2 * half + 1] = pack_bf16(ds[2], ds[3]);
                 }
@@ -1680,11 +1703,11 @@ __global__ void __launch_bounds__(kAttThreads) attention_bwd_kernel(AttArgs a) {
                 const f32x4 l4 = *reinterpret_cast<const f32x4 *>(lseS + 16 * qt + 4 * g);
                 const f32x4 d4 = *reinterpret_cast<const f32x4 *>(DS + 16 * qt + 4 * g);
                 f32x4 pd, ds;
-                const unsigned keep4 = thr ? drop_keep_col4(a.seed, a.stream_id, attn_idx(bh, Sp, 16 * qt + 4 * g, key), (unsigned long long)Sp, thr, lane) : 15u;
+                const Keep4 keep4 = thr ? drop_keep_col4b(a.seed, a.stream_id, attn_idx(bh, Sp, 16 * qt + 4 * g, key), (unsigned long long)Sp, thr, lane) : keep_all();
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const float p = masked ? 0.f : __builtin_amdgcn_exp2f(s[r] * c2 - l4[r]);
-                    const bool keep = (keep4 >> r) & 1u;
+                    const bool keep = keep4.k[r];
                     pd[r] = keep ? p * ks : 0.f;
                     ds[r] = p * ((keep ? dpd[r] * ks : 0.f) - d4[r]) * scale;
                 }
@@ -1814,13 +1837,13 @@ __global__ void __launch_bounds__(kAttThreads, 2) attention_bwd_km_kernel(AttArg
                 for (int c = 0; c < KPW; ++c) {       // key tiles past the slate run too (masked: p = 0) -- no per-tile branches
                         const f32x4 s = mfma_bf16(qa, kf[c], zero);          // S[query 16 qt + 4 g + r][key]
                         const f32x4 dpd = mfma_bf16(da, vf[c], zero);        // dPd[query][key]
-                        const unsigned keep4 = thr ? drop_keep_col4(a.seed, a.stream_id, attn_idx(bh, Sp, 16 * qt + 4 * g, 16 * (w * KPW + c) + j),
-                                                                    (unsigned long long)Sp, thr, lane) : 15u;
+                        const Keep4 keep4 = thr ? drop_keep_col4b(a.seed, a.stream_id, attn_idx(bh, Sp, 16 * qt + 4 * g, 16 * (w * KPW + c) + j),
+                                                                  (unsigned long long)Sp, thr, lane) : keep_all();
                         f32x4 pd, ds;
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
                             const float p = msk[c] ? 0.f : __builtin_amdgcn_exp2f(fmaf(s[r], c2, -l4[r]));
-                            const bool keep = (keep4 >> r) & 1u;
+                            const bool keep = keep4.k[r];
                             pd[r] = keep ? p * ks : 0.f;
                             ds[r] = p * ((keep ? dpd[r] * kss : 0.f) - d4[r]);
                         }

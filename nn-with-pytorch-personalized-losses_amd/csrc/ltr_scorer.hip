@@ -729,6 +729,9 @@ __device__ __forceinline__ void load_x_tile(f32x4 (&xr)[kXV4<N>()], const PipeAr
 #ifndef LTR_XDMA
 #define LTR_XDMA 1
 #endif
+#ifndef LTR_PIPE_ST128_MAXH
+#define LTR_PIPE_ST128_MAXH 64      // widest first hidden layer that gets the slate-128 instantiation (A/B: profiles/r04_variant_ab.json)
+#endif
 #ifndef LTR_PIPE_ST128
 #define LTR_PIPE_ST128 1          // a slate-128 instantiation of the fused approxNDCG pipeline kernels (one loss copy with fixed geometry)
 #endif
@@ -1651,7 +1654,7 @@ int pipeline_dispatch(int mode, const PipeArgs &a, int grid, hipStream_t stream)
                         // a slate-128 instantiation (ONE copy of the loss, fixed geometry) for the narrow nets: 136-64-32 +10.6 %; the
                         // 136-wide kernels, at their register limit, allocate better with the run-time form (0.594 vs 0.579 of the fp32
                         // MFMA peak; profiles/r04_variant_ab.json)
-                        if constexpr (LTR_PIPE_ST128 && N::H1 <= 64) {
+                        if constexpr (LTR_PIPE_ST128 && N::H1 <= LTR_PIPE_ST128_MAXH) {
                             if (a.S == 128) return launch_pipeline<N, MODE_FUSED, 0, 128>(a, grid, stream);
                         }
                         return launch_pipeline<N, MODE_FUSED, 0, 0>(a, grid, stream);

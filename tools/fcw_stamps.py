@@ -16,9 +16,16 @@ B, S = 25_000, 128
 X = torch.randn(B, S, 136, device=dev)
 y = torch.randint(0, 5, (B, S), device=dev).float()
 h = lib()
-net = TwoLayerNet(136).to(dev).eval()
-info = scorer.NetInfo.get(net._ltr_net)
-packed = scorer.pack_params(net._ltr_net, net._ltr_params())
+if len(sys.argv) > 1 and sys.argv[1] == "triplefold":       # the folded TripleLayerNet (two document-split copies of 32 sigmoid units)
+    from architeture.tripleLayer import TripleLayerNet
+    tnet = TripleLayerNet(136).to(dev).eval()
+    pf = scorer._params_f32(tnet._ltr_params())
+    info = scorer.NetInfo.get(scorer.NET_TRIPLE_FOLDED)
+    packed = scorer.pack_params(scorer.NET_TRIPLE_FOLDED, scorer.triple_fold(pf, 2) + [pf[5]])
+else:
+    net = TwoLayerNet(136).to(dev).eval()
+    info = scorer.NetInfo.get(net._ltr_net)
+    packed = scorer.pack_params(net._ltr_net, net._ltr_params())
 for per_cu in (1, 2):
     grid = scorer.cu_count(dev) * per_cu
     part = torch.empty(grid * info.partial_floats, device=dev)

@@ -11,8 +11,8 @@ for it in $items; do
     two64_h)   python3 tools/pmc_summary.py --tag r04_two64_f16x2 --kernel fcw_fused_kernel --lib $H --skip 1 -- bench.py --net two64 $B ;;
     double)    python3 tools/pmc_summary.py --tag r04_double_fp32 --kernel slate_pipeline_kernel --skip 1 -- bench.py --net double $B ;;
     double_h)  python3 tools/pmc_summary.py --tag r04_double_f16x2 --kernel slate_pipeline_kernel --lib $H --skip 1 -- bench.py --net double $B ;;
-    triple)    python3 tools/pmc_summary.py --tag r04_triple_fp32 --kernel slate_pipeline_kernel --skip 1 -- bench.py --net triple $B ;;
-    triple_h)  python3 tools/pmc_summary.py --tag r04_triple_f16x2 --kernel slate_pipeline_kernel --lib $H --skip 1 -- bench.py --net triple $B ;;
+    triple)    python3 tools/pmc_summary.py --tag r04_triple_fp32 --kernel fcw_fused_kernel --skip 1 -- bench.py --net triple $B ;;
+    triple_h)  python3 tools/pmc_summary.py --tag r04_triple_f16x2 --kernel fcw_fused_kernel --lib $H --skip 1 -- bench.py --net triple $B ;;
     approx128) python3 tools/pmc_summary.py --tag r04_loss_approxndcg_S128 --kernel approxndcg_kernel --skip 3 -- tools/bench_losses.py --only approxndcg128 ;;
     approx512) python3 tools/pmc_summary.py --tag r04_loss_approxndcg_S512 --kernel approxndcg_kernel --skip 3 -- tools/bench_losses.py --only approxndcg512 ;;
     lambda128) python3 tools/pmc_summary.py --tag r04_loss_lambda2pp_S128 --kernel lambda_kernel --skip 3 -- tools/bench_losses.py --only lambda128 ;;
