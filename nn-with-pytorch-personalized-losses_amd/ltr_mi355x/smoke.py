@@ -41,4 +41,19 @@ def run(oracle, verbose=True):
     if verbose:
         print(f"[smoke] fused DoubleLayerNet+approxNDCG: loss rel err {e3:.2e}, param-grad max-norm rel err {e4:.2e}")
     assert e3 < 1e-5 and e4 < 1e-5, (e3, e4)
+    # 3) TripleLayerNet: its fused step runs l2 . l1 folded into one layer (tripleLayer.py:14-16 has no activation between them)
+    from architeture.tripleLayer import TripleLayerNet
+    net3 = TripleLayerNet(136)
+    ref3 = {k: v.detach().double().clone().requires_grad_(True) for k, v in net3.state_dict().items()}
+    net3 = net3.to(dev)
+    r3 = FusedRanker(net3, loss="approxNDCG")
+    l3 = r3.step(x.to(dev), y.to(dev))
+    lr3 = oracle.approx_ndcg(oracle.triple_layer_forward(x.double(), ref3).squeeze(-1), y.double())
+    lr3.backward()
+    e5 = _rel(l3.detach().cpu(), lr3.detach())
+    top3 = max(float(v.grad.abs().max()) for v in ref3.values())
+    e6 = max(float((p.grad.cpu().double() - ref3[k].grad).abs().max()) / top3 for k, p in net3.named_parameters())
+    if verbose:
+        print(f"[smoke] fused TripleLayerNet (folded={r3.fold is not None})+approxNDCG: loss rel err {e5:.2e}, param-grad max-norm rel err {e6:.2e}")
+    assert e5 < 1e-5 and e6 < 1e-5, (e5, e6)
     return True
