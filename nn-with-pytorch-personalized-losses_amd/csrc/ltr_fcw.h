@@ -26,6 +26,13 @@
 // 576 MFMAs per wave and tile (18.4 k cycles on its SIMD); no staging of dz through LDS, no weight stream.
 #pragma once
 
+// the sigmoid's reciprocal: v_rcp_f32 (1 ulp) by default.  The backward's h (1 - h) loses RELATIVE accuracy when h is within 1e-4 of
+// 1, but what the parity metric sees is the absolute error of the gradient contribution, g x 6e-8 -- the size of any other fp32
+// rounding of the step; the correctly rounded division (__frcp_rn: ~10 instructions) bought nothing measurable and cost ~7 % of the
+// folded TripleLayerNet tile (profiles/r04_variant_ab.json)
+#ifndef FCW_SIGMOID_RCP
+#define FCW_SIGMOID_RCP ltr_rcp
+#endif
 #ifdef LTR_STAMPS
 #define FCW_STAMP(k)                                                                                          \
     if (a.stamps && lane == 0 && (st - (int)blockIdx.x) / (int)gridDim.x == a.stamp_tile)                      \
@@ -325,7 +332,7 @@ __global__ void __launch_bounds__(kFcwThreads, 2) fcw_fused_kernel(const PipeArg
             for (int r = 0; r < 4; ++r) {
                 float v = h1[T][r] * un;
                 if (N::A1 == ACT_RELU_DROP) v = fmaxf(v, 0.f);
-                else if (N::A1 == ACT_SIGMOID) v = __frcp_rn(1.f + __expf(-v))      /* correctly rounded: h (1 - h) of the backward cancels when h is near 1 */;
+                else if (N::A1 == ACT_SIGMOID) v = FCW_SIGMOID_RCP(1.f + __expf(-v));
                 h1[T][r] = v;
             }
         if (drop) {      // (uniform) training-mode dropout: its own loop, so that the hash arithmetic does not sit in the common path
