@@ -31,9 +31,13 @@ class DoubleLayerNet(nn.Module):
 
     def forward(self, x, c1, c2, keep1=None, keep2=None):
         train = self.training and self.dropout.p > 0       # (p is 0.5 in the reference, doubleLayer.py:60; any p in [0, 1) runs)
+        if self._ltr_net == _scorer.NET_WIDE:               # more than 136 features: library GEMMs (scorer.wide_forward)
+            return _scorer.wide_forward("double", self._ltr_params(), x, train, self.dropout.p, keep1, keep2)
         self._ltr_calls += 1
         return _scorer.mlp_scores(self._ltr_net, self._ltr_params(), x, dropout=_scorer.drop_code(train, self.dropout.p),
                                   seed=_scorer.next_seed(self._ltr_calls), keep1=keep1, keep2=keep2)
 
     def predict(self, x, c1, c2):
+        if self._ltr_net == _scorer.NET_WIDE:
+            return _scorer.wide_forward("double", self._ltr_params(), x, False)
         return _scorer.mlp_scores(self._ltr_net, self._ltr_params(), x, dropout=False)

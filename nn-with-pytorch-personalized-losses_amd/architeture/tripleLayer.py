@@ -22,4 +22,6 @@ class TripleLayerNet(nn.Module):
         return [self.l1.weight, self.l1.bias, self.l2.weight, self.l2.bias, self.l3.weight, self.l3.bias]
 
     def forward(self, x, mask, indices):
+        if self._ltr_net == _scorer.NET_WIDE:               # more than 136 features: library GEMMs, l2 . l1 folded (scorer.wide_forward)
+            return _scorer.wide_forward("triple", self._ltr_params(), x)
         return _scorer.mlp_scores(self._ltr_net, self._ltr_params(), x)

@@ -16,6 +16,7 @@ from ._lib import LtrError, check, lib
 from .functional import _ptr, _stream, require_device
 
 NET_DOUBLE, NET_TRIPLE, NET_DOUBLE_64, NET_TRIPLE_64, NET_TWO_LAYER_64H, NET_TRIPLE_FOLDED, NET_TRIPLE_FOLDED_32 = 0, 1, 2, 3, 4, 5, 6
+NET_WIDE = -1       # more than 136 input features (neither of the reference's collections): see wide_forward
 COMPILED_FEATURES = {136: (NET_DOUBLE, NET_TRIPLE), 64: (NET_DOUBLE_64, NET_TRIPLE_64)}
 
 
@@ -27,9 +28,10 @@ def net_id(kind, n_features):
     which = 0 if kind == "double" else 1
     if n_features in COMPILED_FEATURES:
         return COMPILED_FEATURES[n_features][which]
-    if not 1 <= n_features <= 136:
-        raise NotImplementedError(f"the gfx950 scorer kernels hold a 128-document tile of up to 136 features in LDS; "
-                                  f"input_size {n_features} is not built")
+    if n_features > 136:
+        return NET_WIDE            # wider than the fused kernels' LDS tile: the modules run their layers as library GEMMs (wide_forward)
+    if n_features < 1:
+        raise ValueError(f"input_size must be positive, got {n_features}")
     return COMPILED_FEATURES[64 if n_features <= 64 else 136][which] | (n_features << 8)
 LOSS_APPROXNDCG, LOSS_LISTNET, LOSS_LAMBDA = 0, 1, 2
 _MASK64 = (1 << 64) - 1
@@ -232,6 +234,30 @@ class _MLPScores(torch.autograd.Function):
         return (None, None, None, None, None, None) + tuple(grads)
 
 
+def wide_forward(kind, params, x, train=False, p=0.5, keep1=None, keep2=None):
+    """FC scorers with MORE than 136 input features (doubleLayer.py:55-60 / tripleLayer.py:6-10 accept any width; the reference's
+    collections have 136 and 64): the fused slate kernels hold a 128-document tile of at most 136 features in LDS, so these widths run
+    layer by layer on the device as plain library GEMMs (rocBLAS through torch.nn.functional.linear -- the one place the hand-written
+    kernels are not used) with autograd's own backward.  DoubleLayerNet: fc1, ReLU, dropout, fc2, ReLU, dropout, fc3 -- torch's
+    dropout in training mode (exactly the reference's stream), or the explicit keep masks.  TripleLayerNet: l2 . l1 folded into one
+    layer (no activation between them, tripleLayer.py:14-15), sigmoid, l3.  The listwise losses on the resulting scores are the HIP
+    kernels as always; FusedRanker does not take these networks."""
+    import torch.nn.functional as Fn
+    require_device(x, *params)
+    if kind == "triple":
+        W1, b1, W2, b2, w3, b3 = params
+        return Fn.linear(torch.sigmoid(Fn.linear(x, W2 @ W1, W2 @ b1 + b2)), w3, b3)
+    W1, b1, W2, b2, w3, b3 = params
+
+    def drop(h, keep):
+        if keep is not None:
+            return h * keep.to(h.dtype).reshape(h.shape) * (1.0 / (1.0 - p))
+        return Fn.dropout(h, p, training=train)
+    h = drop(torch.relu(Fn.linear(x, W1, b1)), keep1)
+    h = drop(torch.relu(Fn.linear(h, W2, b2)), keep2)
+    return Fn.linear(h, w3, b3)
+
+
 def mlp_scores(net, params, x, dropout=False, seed=0, keep1=None, keep2=None):
     """scores[..., 1] = net(x) on the device.  x: [..., F] fp32 device tensor.  No gradient w.r.t. x."""
     require_device(x, *params)
@@ -291,6 +317,9 @@ class FusedRanker:
         if loss not in self.LOSSES:
             raise KeyError(f"fused loss must be one of {sorted(self.LOSSES)}, got {loss!r}")
         self.module = module
+        if module._ltr_net == NET_WIDE:
+            raise NotImplementedError("the fused step is built for scorers of up to 136 input features; wider networks run as "
+                                      "net(x, None, None) + the loss + backward() (ltr_mi355x.scorer.wide_forward)")
         self.info = NetInfo.get(module._ltr_net)
         self.net = self.info.net           # the compiled network id the kernels run
         self.loss = loss

@@ -376,8 +376,44 @@ def test_64_feature_nets(kind, S, dev):
         scores = net(x.to(dev), None, None)
     approxNDCGLoss(scores.squeeze(-1), y.to(dev)).backward()
     assert_grads(_grads(net), fused, 1e-5)
-    with pytest.raises(NotImplementedError):
-        _make(kind, dev, 1, F=220)
+
+
+@pytest.mark.parametrize("kind", ["triple", "double"])
+def test_wider_than_136_features_runs_on_library_gemms(kind, dev):
+    """doubleLayer.py:55-60 / tripleLayer.py:6-10 accept any width: beyond the fused kernels' 136-feature tile the layers run as
+    library GEMMs on the device (scorer.wide_forward; TripleLayerNet with l2 . l1 folded), the listwise loss is the HIP kernel as
+    always -- scores, loss and every gradient against the fp64 oracle; FusedRanker refuses these networks with a clear message."""
+    from losses.approxNDCG import approxNDCGLoss
+    from ltr_mi355x.scorer import FusedRanker
+    F = 220
+    net, sd = _make(kind, dev, 1, F=F)
+    gen = torch.Generator().manual_seed(F)
+    B, S = 7, 50
+    x = torch.randn(B, S, F, generator=gen)
+    y = torch.randint(0, 5, (B, S), generator=gen).float()
+    y[1, 40:] = -1.0
+    k1 = (torch.rand(B * S, F, generator=gen) > 0.5)
+    k2 = (torch.rand(B * S, F, generator=gen) > 0.5)
+    net.train()
+    if kind == "double":
+        scores = net(x.to(dev), None, None, keep1=k1.to(dev), keep2=k2.to(dev))
+    else:
+        scores = net(x.to(dev), None, None)
+    loss = approxNDCGLoss(scores.squeeze(-1), y.to(dev))
+    loss.backward()
+    kk = (k1.float().view(B, S, F), k2.float().view(B, S, F)) if kind == "double" else (None, None)
+    rl, rg, rs = _oracle_step(kind, sd, x, y, "approxNDCG", *kk)
+    _, rg32, _ = _oracle_step(kind, sd, x, y, "approxNDCG", *kk, dtype=torch.float32)
+    assert relerr(scores.detach().squeeze(-1).cpu().numpy(), rs) < TOL
+    assert relerr(loss.detach().cpu().numpy(), rl) < TOL
+    assert_grads(_grads(net), rg, ref32=rg32)
+    if kind == "double":                          # eval mode / predict: no dropout
+        net.eval()
+        se = net(x.to(dev), None, None)
+        assert torch.equal(se, net.predict(x.to(dev), None, None))
+        assert relerr(se.detach().squeeze(-1).cpu().numpy(), _oracle_step(kind, sd, x, y, "approxNDCG")[2]) < TOL
+    with pytest.raises(NotImplementedError, match="136"):
+        FusedRanker(net, loss="approxNDCG")
 
 
 @pytest.mark.parametrize("kind,F", [("double", 100), ("double", 46), ("double", 5), ("triple", 100), ("triple", 46), ("triple", 72)])
