@@ -89,11 +89,13 @@ def test_scorer_modules_construct_on_cpu():
         assert isinstance(d.dropout, torch.nn.Dropout) and d.dropout.p == 0.5
     d = DoubleLayerNet(100)                       # any input size up to 136 runs zero-padded on a compiled geometry
     assert tuple(d.fc2.weight.shape) == (100, 100) and tuple(TripleLayerNet(46).l1.weight.shape) == (64, 46)
-    with pytest.raises(NotImplementedError):
-        DoubleLayerNet(220)                       # a 128-document tile of more than 136 features does not fit LDS
+    w = DoubleLayerNet(220)                       # wider than the fused kernels' tile: library-GEMM path (scorer.wide_forward), still device-only
+    assert tuple(w.fc1.weight.shape) == (220, 220) and tuple(TripleLayerNet(300).l1.weight.shape) == (64, 300)
     from ltr_mi355x import LtrDeviceError
     with pytest.raises(LtrDeviceError):
         TripleLayerNet(136)(torch.zeros(2, 4, 136), None, None)
+    with pytest.raises(LtrDeviceError):
+        w(torch.zeros(2, 4, 220), None, None)     # no CPU path for the wide networks either
 
 
 def test_module_surface_matches_reference():
