@@ -5,6 +5,7 @@ whole network is ONE fused forward/backward; every block can also be called on i
 (ltr_mi355x/blocks.py: one autograd node per block over the same C-ABI entry points, gradients to parameters and inputs).
 Device tensors only.  `mask`: per-document padding ([batch, slate], optionally with singleton head / query axes)."""
 import copy
+import math
 
 import torch
 import torch.nn as nn
@@ -71,6 +72,14 @@ class MultiHeadedAttention(nn.Module):
         materialised on this path: it stays None -- `attention()` returns the map when it is wanted."""
         B = _blocks()
         nb, S = query.shape[0], query.shape[1]
+        if _general_shapes(query, key, value, mask, nb, S, 1):
+            # key / value sets unlike the query set, or a mask that is not one flag per document (the reference's own callers pass
+            # neither): the reference's formulation (:196-212) on the device, as library GEMMs + ATen softmax -- see attention()
+            B.require_device(query, key, value)
+            m = mask.unsqueeze(1) if mask is not None else None
+            q, k, v = [lin(x).view(nb, -1, self.h, self.d_k).transpose(1, 2) for lin, x in zip(self.linears, (query, key, value))]
+            x, self.attn = _attention_general(q, k, v, m, self.dropout)
+            return self.linears[-1](x.transpose(1, 2).contiguous().view(nb, -1, self.h * self.d_k))
         m8 = B.slate_mask(mask, nb, S, query.device)
         p = self.dropout.p if self.training else 0.0
         same = key is query and value is query
@@ -165,12 +174,37 @@ class Encoder(nn.Module):
                     enc_dropout=l0.sublayer[0].dropout.p)
 
 
+def _general_shapes(query, key, value, mask, nb, S, seq_axis):
+    """True when the fused attention kernels do not apply: key / value of another shape than the query, or a mask that is not one
+    padding flag per document (anything but nb * S elements)."""
+    if tuple(key.shape) != tuple(query.shape) or tuple(value.shape) != tuple(query.shape):
+        return True
+    return mask is not None and mask.numel() != nb * S
+
+
+def _attention_general(query, key, value, mask, dropout):
+    """transformer.py:154-163 literally, on device tensors: rocBLAS batched GEMMs + ATen softmax / dropout with autograd's backward.
+    The shapes the reference's own callers use never come here (they run the fused HIP kernels)."""
+    d_k = query.size(-1)
+    scores = torch.matmul(query, key.transpose(-2, -1)) / math.sqrt(d_k)
+    if mask is not None:
+        scores = scores.masked_fill(mask == 1, float("-inf"))
+    p_attn = torch.softmax(scores, dim=-1)
+    if dropout is not None:
+        p_attn = dropout(p_attn)
+    return torch.matmul(p_attn, value), p_attn
+
+
 def attention(query, key, value, mask=None, dropout=None):
     """transformer.py:145-164: query / key / value [batch, heads, slate, d_k] -> (output [batch, heads, slate, d_k], p_attn
     [batch, heads, slate, slate]).  `dropout`: None or an nn.Dropout module (applied to p_attn when it is in training mode).
-    The output carries the analytic backward (ltr_enc_attention_bwd); p_attn is returned detached."""
+    The output carries the analytic backward (ltr_enc_attention_bwd); p_attn is returned detached.  Key / value sets shaped unlike the
+    query set and masks other than one flag per document take the reference's formulation on the device (_attention_general)."""
     B = _blocks()
     nb, h, S, dk = query.shape
+    if _general_shapes(query, key, value, mask, nb, S, 2):
+        B.require_device(query, key, value)
+        return _attention_general(query, key, value, mask, dropout)
     m8 = B.slate_mask(mask, nb, S, query.device)
     p = float(dropout.p) if (dropout is not None and getattr(dropout, "training", False)) else 0.0
     seed = B.fresh_seed() if p > 0 else 0

@@ -166,8 +166,8 @@ def _composite_gate(case, g, mod, ins, out, pairs, w_out):
 
 
 def test_blocks_train_mode_and_errors():
-    """Dropout sites are live in train mode (outputs change between calls, eval is deterministic); shapes the HIP path does
-    not cover raise instead of silently computing something else."""
+    """Dropout sites are live in train mode (outputs change between calls, eval is deterministic); attention shapes outside the fused
+    kernels' run the reference's formulation on the device; CPU tensors raise."""
     from architeture import transformer as T
     torch.manual_seed(0)
     x = torch.randn(2, 16, 32, device=DEV)
@@ -180,11 +180,37 @@ def test_blocks_train_mode_and_errors():
     assert torch.equal(enc(x, mask, None), enc(x, mask, None))
     with pytest.raises(AttributeError):
         enc(x, None, None)                                        # transformer.py:55 dereferences the mask
+    # key / value sets unlike the query set and masks that are not one flag per document (transformer.py:145-164, :187-212 take them;
+    # the reference's own callers never pass either): the reference's formulation on the device -- checked against the same
+    # lines restated in fp64 on the CPU, values and gradients
+    import math
     mha = T.MultiHeadedAttention(4, 32, 0.0).to(DEV).eval()
-    with pytest.raises(NotImplementedError):
-        mha(x, x, x, torch.zeros(2, 16, 16, device=DEV))           # per-query masks are not a padding mask
-    with pytest.raises(NotImplementedError):
-        mha(x, x[:, :8], x[:, :8], None)
+
+    def ref_mha(q, k, v, m):
+        W = [(l.weight.detach().double().cpu(), l.bias.detach().double().cpu()) for l in mha.linears]
+        nb = q.shape[0]
+        qq, kk, vv = [(t @ w.T + b).view(nb, -1, 4, 8).transpose(1, 2) for t, (w, b) in zip((q, k, v), W[:3])]
+        sc = qq @ kk.transpose(-2, -1) / math.sqrt(8)
+        if m is not None:
+            sc = sc.masked_fill(m.unsqueeze(1) == 1, float("-inf"))
+        o = (torch.softmax(sc, -1) @ vv).transpose(1, 2).contiguous().view(nb, -1, 32)
+        return o @ W[3][0].T + W[3][1]
+    pq = torch.zeros(2, 16, 16, device=DEV)
+    pq[:, :, 12:] = 1                                          # a [batch, query, key] mask
+    for k_in, m in ((x, pq), (x[:, :8], None)):
+        xq = x.clone().requires_grad_(True)
+        out = mha(xq, k_in, k_in, m)
+        out.square().sum().backward()
+        xr = x.detach().double().cpu().requires_grad_(True)
+        ref = ref_mha(xr, k_in.detach().double().cpu(), k_in.detach().double().cpu(), None if m is None else m.cpu())
+        ref.square().sum().backward()
+        assert relerr(out.detach().cpu().numpy(), ref.detach().numpy()) < 2e-5
+        assert relerr(xq.grad.cpu().numpy(), xr.grad.numpy()) < 2e-5
+    o2, p2 = T.attention(torch.randn(2, 4, 16, 8, device=DEV), torch.randn(2, 4, 5, 8, device=DEV), torch.randn(2, 4, 5, 8, device=DEV))
+    assert tuple(o2.shape) == (2, 4, 16, 8) and tuple(p2.shape) == (2, 4, 16, 5)
+    from ltr_mi355x._lib import LtrDeviceError as _DevErr
+    with pytest.raises(_DevErr):
+        T.attention(torch.randn(2, 4, 16, 8), torch.randn(2, 4, 5, 8), torch.randn(2, 4, 5, 8))      # no CPU path here either
     from ltr_mi355x._lib import LtrDeviceError
     with pytest.raises(LtrDeviceError):
         T.LayerNorm(32)(x.cpu())
