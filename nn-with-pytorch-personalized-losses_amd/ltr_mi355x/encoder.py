@@ -203,11 +203,20 @@ def attention_bwd(qkv, ctxb, dctx, lse, mask_u8, B, S, h, dk, p, seed, stream_id
     return dqkv
 
 
-def fused_ffn_enabled(d, dff):
+FUSED_FFN_MIN_TOKENS = 8193     # below this the GEMM path is faster (measured, profiles/r04_c5_graph_step.jsonl)
+
+
+def fused_ffn_enabled(d, dff, T=None):
     """The fused FFN kernels (no [T, d_ff] tensor in HBM) cover d_model in {64, 128} with d_ff a multiple of 128;
-    LTR_ENC_FUSED_FFN=0 forces the GEMM path (A/B measurements, tests)."""
+    LTR_ENC_FUSED_FFN=0 forces the GEMM path, =1 the fused kernels (A/B measurements, tests).  Unset: fused from 8 193 tokens per
+    step -- a fused-FFN workgroup walks all d_ff chunks of its 128 tokens serially, so 4 096 tokens are 32 workgroups on 256 CUs,
+    while the GEMM path tiles the same work over 512 and its hidden tensor (16 MB there) is no traffic to speak of: the graphed
+    config-5 step at 16 slates runs 2.05 ms on GEMMs against 2.35 fused, at 32 slates 2.45 / 2.54, at 64 slates 3.11 / 2.96."""
     import os
-    return os.environ.get("LTR_ENC_FUSED_FFN", "1") != "0" and bool(lib().ltr_enc_ffn_supported(int(d), int(dff)))
+    env = os.environ.get("LTR_ENC_FUSED_FFN")
+    if env == "0" or not lib().ltr_enc_ffn_supported(int(d), int(dff)):
+        return False
+    return env == "1" or T is None or int(T) >= FUSED_FFN_MIN_TOKENS
 
 
 def ffn_fwd(n2, w1, b1, w2, b2, x1, T, d, dff, p, seed, s_hidden, s_out):
@@ -327,7 +336,7 @@ def _run_forward(spec, x, mask, seed, training, params):
         mask_u8 = (mask.to(dev) == 1).to(torch.uint8).contiguous().view(B, S)
         st["mask_u8"] = mask_u8
         h, dk, dff = spec.heads, spec.dk, spec.d_ff
-        st["fused_ffn"] = fused_ffn_enabled(d, dff)
+        st["fused_ffn"] = fused_ffn_enabled(d, dff, T)
         # all encoder weights to bf16 in ONE cast: [Wq | Wk | Wv | Wo | W1 | W2] per block, concatenated (every piece is a
         # multiple of 8 elements, so the views stay 16-byte aligned)
         n_fc_prm = (2 if spec.input_norm else 0) + 2 * len(spec.fc_sizes)

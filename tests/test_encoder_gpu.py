@@ -621,6 +621,45 @@ def test_network_train_mode_dropout_matches_oracle_under_exported_masks(enc):
     assert torch.equal(net(x, mask, None), net(x, mask, None))
 
 
+def test_small_steps_take_the_gemm_ffn_path_by_default(enc, monkeypatch):
+    """Below 8 193 tokens per step the encoder's FFN runs as two GEMMs (faster there: a fused-FFN workgroup walks all d_ff chunks of
+    its tokens serially), from there on fused; LTR_ENC_FUSED_FFN = 0 / 1 force either.  The two paths agree on a whole training step
+    under the same dropout seed (bf16 operands on both: scores to 1e-2 of their range, every gradient to 5e-2 of its max-norm)."""
+    from architeture.multiLayer import make_model
+    from losses.approxNDCG import approxNDCGLoss
+    from ltr_mi355x import blocks, encoder as E
+    from architeture.multiLayer import LTRModel
+    monkeypatch.delenv("LTR_ENC_FUSED_FFN", raising=False)
+    assert not E.fused_ffn_enabled(128, 2048, 4096) and E.fused_ffn_enabled(128, 2048, 8193) and E.fused_ffn_enabled(128, 2048)
+    assert not E.fused_ffn_enabled(136, 2048, 1 << 20)            # d_model outside {64, 128}: never
+    monkeypatch.setenv("LTR_ENC_FUSED_FFN", "0")
+    assert not E.fused_ffn_enabled(128, 2048, 1 << 20)
+    monkeypatch.setenv("LTR_ENC_FUSED_FFN", "1")
+    assert E.fused_ffn_enabled(128, 2048, 16)
+    monkeypatch.setattr(LTRModel, "_ltr_next_seed", lambda self: 77)
+    torch.manual_seed(5)
+    net = make_model(dict(sizes=[128], input_norm=False, activation=None, dropout=0.0), dict(N=2, d_ff=512, h=8, dropout=0.1,
+                     positional_encoding=None), dict(d_output=1, output_activation=None), 136).to(DEV).train()
+    x = torch.randn(6, 64, 136, device=DEV)
+    y = torch.randint(0, 5, (6, 64), device=DEV).float()
+    mask = torch.zeros(6, 64, dtype=torch.bool, device=DEV)
+    res = []
+    for env in ("1", None):                                       # fused (forced) / default = GEMMs at 384 tokens
+        if env is None:
+            monkeypatch.delenv("LTR_ENC_FUSED_FFN", raising=False)
+        else:
+            monkeypatch.setenv("LTR_ENC_FUSED_FFN", env)
+        net.zero_grad()
+        s_ = net(x, mask, None)
+        approxNDCGLoss(s_, y).backward()
+        res.append((s_.detach().clone(), {k: p.grad.clone() for k, p in net.named_parameters()}))
+    (sa, ga), (sb, gb) = res
+    assert float((sa - sb).abs().max() / sa.abs().max()) < 1e-2
+    top = max(float(v.abs().max()) for v in ga.values())
+    for k in ga:                                                  # (the key bias has an exactly-zero gradient: noise against the top gradient)
+        assert float((ga[k] - gb[k]).abs().max()) / max(float(ga[k].abs().max()), 1e-2 * top) < 5e-2, k
+
+
 def test_network_api_errors_and_features(enc):
     from architeture.multiLayer import make_model
     from ltr_mi355x._lib import LtrDeviceError
