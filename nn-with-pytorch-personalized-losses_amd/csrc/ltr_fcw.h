@@ -154,19 +154,40 @@ __global__ void __launch_bounds__(kFcwThreads, 2) fcw_fused_kernel(const PipeArg
 
     constexpr int V4_PER_ROW = N::F / 4, ROWS = kTileDocs / kFcwWaves, V4 = ROWS * V4_PER_ROW;   // this wave converts 32 rows
     constexpr int NV = (V4 + 63) / 64;
+    // Which 16-byte piece of the wave's 32 rows a lane takes in load m.  XPAIR = false: piece lane + 64 m of the contiguous block (1 KiB
+    // per load; row = e / 34, column = e % 34).  XPAIR = true: two rows x 32 columns per load for m < NV - 1 (row 2 m + lane / 32, column
+    // lane % 32) and the two left-over columns of all 32 rows in the last load (row lane / 2, column 32 + lane % 2): every global and
+    // LDS address is one lane constant plus an immediate, and the LDS stores of a load land in two rows instead of straddling three.
+    // Measured (profiles/r04_variant_ab.json, r4ae): 136-64-1 exact fp32 +4.5 %, its f16 x 2 variant +2.3 %, folded TripleLayerNet
+    // exact +0.7 %, its f16 x 2 variant -4 % (the one kernel fast enough to feel the 32-byte runs of the tail load) -- hence:
+    constexpr bool XPAIR = !(LTR_F16X2 && N::DS == 2);
+    constexpr int XMAIN = 32, XTAIL = V4_PER_ROW - XMAIN;
+    static_assert(V4 % 64 == 0, "the wave's row block is a whole number of 1 KiB wave loads");
+    static_assert(!XPAIR || (XTAIL > 0 && ROWS * XTAIL == 64 && NV == ROWS / 2 + 1), "16 two-row loads and one tail load per wave and tile");
+    const int xrow_main = lane >> 5, xcol_main = lane & 31, xrow_tail = lane / XTAIL, xcol_tail = XMAIN + lane % XTAIL;
+    // (row, 4-float column) of this lane's piece of load m
+    auto x_row = [&](int m) { return XPAIR ? (m < NV - 1 ? 2 * m + xrow_main : xrow_tail) : (lane + 64 * m) / V4_PER_ROW; };
+    auto x_col = [&](int m) { return XPAIR ? (m < NV - 1 ? xcol_main : xcol_tail) : (lane + 64 * m) % V4_PER_ROW; };
     f32x4 xn[NV];
     auto load_x = [&](int tile) {
         // one buffer descriptor per wave and tile, sized to the rows that exist: the hardware bounds check returns zeros for
         // rows past the end of the batch (no per-element compare, no 64-bit address registers)
-        static_assert(V4 % 64 == 0, "the wave's row block is a whole number of 1 KiB wave loads");
         const long long row0 = (long long)tile * kTileDocs + ROWS * w;
         long long rows_here = a.n_docs - row0;
         rows_here = rows_here < 0 ? 0 : (rows_here > ROWS ? ROWS : rows_here);
         const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.X + (rows_here ? row0 : 0) * N::F), 0,
                                                                              (int)rows_here * N::F * 4, 0x00020000);
+        if (XPAIR) {
+            const int lo = (xrow_main * N::F + 4 * xcol_main) * 4;
 #pragma unroll
-        for (int m = 0; m < NV; ++m)
-            xn[m] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xr, lane * 16 + m * 1024, 0, 2 /* nt */));
+            for (int m = 0; m < NV - 1; ++m)
+                xn[m] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xr, lo + m * (2 * N::F * 4), 0, 2 /* nt */));
+            xn[NV - 1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xr, (xrow_tail * N::F + 4 * xcol_tail) * 4, 0, 2));
+        } else {
+#pragma unroll
+            for (int m = 0; m < NV; ++m)
+                xn[m] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xr, lane * 16 + m * 1024, 0, 2 /* nt */));
+        }
     };
 #if FCW_X_PREFETCH == 1
     if ((int)blockIdx.x < a.n_super) load_x(blockIdx.x);
@@ -228,14 +249,11 @@ __global__ void __launch_bounds__(kFcwThreads, 2) fcw_fused_kernel(const PipeArg
             const float sx = ldexpf(1.f, 14 - exx);
 #pragma unroll
             for (int m = 0; m < NV; ++m) {
-                const int e = lane + 64 * m;
-                if (e < V4) {
-                    u32x2 hi, lo;
-                    split4(xn[m], sx, hi, lo);
-                    const int off = (ROWS * w + e / V4_PER_ROW) * LDH + 4 * (e % V4_PER_ROW);
-                    *reinterpret_cast<u32x2 *>(Xhi + off) = hi;
-                    *reinterpret_cast<u32x2 *>(Xlo + off) = lo;
-                }
+                u32x2 hi, lo;
+                split4(xn[m], sx, hi, lo);
+                const int off = (ROWS * w + x_row(m)) * LDH + 4 * x_col(m);
+                *reinterpret_cast<u32x2 *>(Xhi + off) = hi;
+                *reinterpret_cast<u32x2 *>(Xlo + off) = lo;
             }
             if (lane < ROWS) {
                 Xhi[(ROWS * w + lane) * LDH + N::F] = __builtin_bit_cast(uint16_t, (_Float16)sx);
@@ -245,10 +263,8 @@ __global__ void __launch_bounds__(kFcwThreads, 2) fcw_fused_kernel(const PipeArg
 #else
         FCW_STAMP(2)
 #pragma unroll
-        for (int m = 0; m < NV; ++m) {                // rows of F floats -> rows of LDX floats (the pads were written once)
-            const int e = lane + 64 * m;
-            if (e < V4) *reinterpret_cast<f32x4 *>(Xs + (ROWS * w + e / V4_PER_ROW) * LDX + 4 * (e % V4_PER_ROW)) = xn[m];
-        }
+        for (int m = 0; m < NV; ++m)                  // rows of F floats -> rows of LDX floats (the pads were written once)
+            *reinterpret_cast<f32x4 *>(Xs + (ROWS * w + x_row(m)) * LDX + 4 * x_col(m)) = xn[m];
 #endif
         __syncthreads();                              // C: the tile is complete in LDS
         FCW_STAMP(3)
