@@ -205,20 +205,23 @@ enum { LTR_NET_DOUBLE = 0, LTR_NET_TRIPLE = 1,         /* 136 input features (MS
                                         no activation between them): a two-layer net [64 x 136 | 64 | 64 | 1] whose rows 32..63
                                         repeat rows 0..31 (each copy runs on half of a tile's documents).  Parameters from
                                         ltr_triple_fold, gradients back through ltr_triple_unfold_grads.  ltr_fused_step* only. */
-       LTR_NET_TRIPLE_FOLDED_32 = 6 }; /* the same folded network as a plain two-layer net [32 x 136 | 32 | 32 | 1] (copies = 1) for
+       LTR_NET_TRIPLE_FOLDED_32 = 6,   /* the same folded network as a plain two-layer net [32 x 136 | 32 | 32 | 1] (copies = 1) for
                                         ltr_mlp_forward / _backward / _forward_save / _backward_saved. */
+       LTR_NET_TRIPLE_FOLDED_32_64 = 7 }; /* TripleLayerNet on 64 features (TD2003) folded: [32 x 64 | 32 | 32 | 1], every entry
+                                        point (its fused step runs on the generic pipeline). */
 enum { LTR_LOSS_APPROXNDCG = 0, LTR_LOSS_LISTNET = 1 };
 
-/* TripleLayerNet (136 features) -> its folded two-layer form, fp64 accumulation; R = 32 copies rows (copies = 2: LTR_NET_TRIPLE_FOLDED,
- * copies = 1: LTR_NET_TRIPLE_FOLDED_32):
- *   W1e [R][136]: rows c 32 + u = (W2 W1)[u];  b1e [R] = (W2 b1 + b2)[u];  w3e [R] = w3[u]  (u < 32, c < copies).
- * Once per step (weights change every step): 32 x 64 x 137 multiply-adds. */
-int ltr_triple_fold(const float *W1, const float *b1, const float *W2, const float *b2, const float *w3, int copies, float *W1e,
+/* TripleLayerNet (F input features) -> its folded two-layer form, fp64 accumulation; R = 32 copies rows (copies = 2: LTR_NET_TRIPLE_FOLDED,
+ * copies = 1: LTR_NET_TRIPLE_FOLDED_32 / _32_64):
+ *   W1e [R][F]: rows c 32 + u = (W2 W1)[u];  b1e [R] = (W2 b1 + b2)[u];  w3e [R] = w3[u]  (u < 32, c < copies).
+ * Once per step (weights change every step): 32 x 64 x (F + 1) multiply-adds. */
+int ltr_triple_fold(const float *W1, const float *b1, const float *W2, const float *b2, const float *w3, int F, int copies, float *W1e,
                     float *b1e, float *w3e, void *stream);
-/* The flat gradient of the folded net, g2 = [dW1e R x 136 | db1e R | dw3e R | db3], -> TripleLayerNet's flat gradient
- * [dW1 64 x 136 | db1 64 | dW2 32 x 64 | db2 32 | dw3 32 | db3]: with G[u] = sum_c dW1e[c 32 + u], gb[u] = sum_c db1e[c 32 + u],
+/* The flat gradient of the folded net, g2 = [dW1e R x F | db1e R | dw3e R | db3], -> TripleLayerNet's flat gradient
+ * [dW1 64 x F | db1 64 | dW2 32 x 64 | db2 32 | dw3 32 | db3]: with G[u] = sum_c dW1e[c 32 + u], gb[u] = sum_c db1e[c 32 + u],
  *   dW1 = W2^T G, db1 = W2^T gb, dW2 = G W1^T + gb b1^T, db2 = gb, dw3[u] = sum_c dw3e[c 32 + u].  fp64 accumulation. */
-int ltr_triple_unfold_grads(const float *g2, int copies, const float *W1, const float *b1, const float *W2, float *flat, void *stream);
+int ltr_triple_unfold_grads(const float *g2, int F, int copies, const float *W1, const float *b1, const float *W2, float *flat,
+                            void *stream);
 
 /* info[0..7] = F, H1, H2, n_params, packed_floats, partial_floats (per workgroup), docs_per_tile, lds_bytes */
 int ltr_net_info(int net, int32_t *info);

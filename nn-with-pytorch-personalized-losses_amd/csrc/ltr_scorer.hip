@@ -134,10 +134,13 @@ using TripleFolded = NetT<136, 64, 64, ACT_SIGMOID, ACT_SIGMOID, 2, 2, true, 2>;
 // the same folded network as a plain 136 -> 32 -> 1 two-layer net for the generic pipeline's forward / backward launches (module path
 // `net(x)`, slates other than 32 / 64 / 128): MODE_FWD / MODE_BWD / MODE_BWD_SAVED only
 using TripleFolded32 = NetT<136, 32, 32, ACT_SIGMOID, ACT_SIGMOID, 2, 2, true>;
+// ... and on the 64-feature collection (TD2003): every path of that network, the one-launch step included (generic pipeline)
+using TripleFolded32F64 = NetT<64, 32, 32, ACT_SIGMOID, ACT_SIGMOID, 2, 2, true>;
 #define LTR_FOR_NET_EXTRA(...)                                                              \
     case LTR_NET_TWO_LAYER_64H: { using NET = TwoLayerNet64h; __VA_ARGS__; } break;         \
     case LTR_NET_TRIPLE_FOLDED: { using NET = TripleFolded; __VA_ARGS__; } break;           \
-    case LTR_NET_TRIPLE_FOLDED_32: { using NET = TripleFolded32; __VA_ARGS__; } break;
+    case LTR_NET_TRIPLE_FOLDED_32: { using NET = TripleFolded32; __VA_ARGS__; } break;     \
+    case LTR_NET_TRIPLE_FOLDED_32_64: { using NET = TripleFolded32F64; __VA_ARGS__; } break;
 
 // run the statement(s) given after `net` with NET bound to the network type of id `net` (LTR_NET_*); unknown ids ->
 // LTR_ERR_PARAM.  Variadic: the statement may contain top-level commas (kernel launches).
@@ -1513,10 +1516,10 @@ __global__ void pack_kernel(const float *__restrict__ W1, const float *__restric
 // Sum the per-workgroup partials in a fixed order and scatter into the flat gradient
 // [W1 (H1 x F) | b1 (H1) | W2 (H2 x H1) | b2 (H2) | w3 (H2) | b3 (1)]  (= nn.Module parameter order).
 // ---- TripleLayerNet <-> its folded two-layer form (see TripleFolded) ------------------------------------------------------
-constexpr int kTrF = 136, kTrH1 = 64, kTrH2 = 32;
+constexpr int kTrH1 = 64, kTrH2 = 32;       // TripleLayerNet's hidden widths (tripleLayer.py:8-10); the input width F is a run-time argument
 __global__ void triple_fold_kernel(const float *__restrict__ W1, const float *__restrict__ b1, const float *__restrict__ W2,
-                                   const float *__restrict__ b2, const float *__restrict__ w3, int copies, float *__restrict__ W1e,
-                                   float *__restrict__ b1e, float *__restrict__ w3e) {
+                                   const float *__restrict__ b2, const float *__restrict__ w3, int kTrF, int copies,
+                                   float *__restrict__ W1e, float *__restrict__ b1e, float *__restrict__ w3e) {
     const int e = blockIdx.x * blockDim.x + threadIdx.x;           // one thread per element of [32][136 + 1]
     if (e >= kTrH2 * (kTrF + 1)) return;
     const int u = e / (kTrF + 1), f = e % (kTrF + 1);
@@ -1532,14 +1535,14 @@ __global__ void triple_fold_kernel(const float *__restrict__ W1, const float *__
         }
     }
 }
-__global__ void triple_unfold_kernel(const float *__restrict__ g2, int copies, const float *__restrict__ W1, const float *__restrict__ b1,
+__global__ void triple_unfold_kernel(const float *__restrict__ g2, int kTrF, int copies, const float *__restrict__ W1, const float *__restrict__ b1,
                                      const float *__restrict__ W2, float *__restrict__ flat) {
     // g2 = [dW1e R x 136 | db1e R | dw3e R | db3], R = 32 copies;  flat = [dW1 64 x 136 | db1 64 | dW2 32 x 64 | db2 32 | dw3 32 | db3]
     const int R = kTrH2 * copies;
     const float *gW = g2, *gb = g2 + R * kTrF, *gw3 = gb + R, *gb3 = gw3 + R;
     auto G = [&](int u, int f) { double v = 0.0; for (int c = 0; c < copies; ++c) v += (double)gW[(c * kTrH2 + u) * kTrF + f]; return v; };
     auto Gb = [&](int u) { double v = 0.0; for (int c = 0; c < copies; ++c) v += (double)gb[c * kTrH2 + u]; return v; };
-    constexpr int nW1 = kTrH1 * kTrF, nb1 = kTrH1, nW2 = kTrH2 * kTrH1, nb2 = kTrH2, nw3 = kTrH2;
+    const int nW1 = kTrH1 * kTrF, nb1 = kTrH1, nW2 = kTrH2 * kTrH1, nb2 = kTrH2, nw3 = kTrH2;
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
     int k = e;
     if (k < nW1) {                                   // dW1[h][f] = sum_u W2[u][h] G[u][f]
@@ -1640,9 +1643,9 @@ int pipeline_dispatch(int mode, const PipeArgs &a, int grid, hipStream_t stream)
         case MODE_BWD: if constexpr (N::DS == 1) return launch_pipeline<N, MODE_BWD, 0>(a, grid, stream); else return LTR_ERR_PARAM;
         case MODE_BWD_SAVED: if constexpr (N::DS == 1) return launch_pipeline<N, MODE_BWD_SAVED, 0>(a, grid, stream); else return LTR_ERR_PARAM;
         default:
-            if constexpr (N::TWO && N::H1 != 64) {
-                return LTR_ERR_PARAM;    // (the fused two-layer kernel has one 16-unit hidden tile per wave: 64 hidden rows)
-            } else if constexpr (N::TWO) {      // two-layer nets: the feature-partitioned kernel, two workgroups per CU (ltr_fcw.h)
+            if constexpr (N::TWO && N::H1 != 64 && N::F == 136) {
+                return LTR_ERR_PARAM;    // (136 features: the fused step runs the document-split form on ltr_fcw.h, TripleFolded)
+            } else if constexpr (N::TWO && N::H1 == 64) {      // two-layer nets: the feature-partitioned kernel, two workgroups per CU (ltr_fcw.h)
                 switch (a.loss_kind) {
                     case 0: return launch_fcw<N, 0>(a, grid, stream);
                     case 1: return launch_fcw<N, 1>(a, grid, stream);
@@ -1681,7 +1684,7 @@ int ltr_net_info(int net, int32_t *info) {
 
 int ltr_fused_grid(int net, int n_cus) {
     if (n_cus < 1) return LTR_ERR_PARAM;
-    if (net < LTR_NET_DOUBLE || net > LTR_NET_TRIPLE_FOLDED_32) return LTR_ERR_PARAM;
+    if (net < LTR_NET_DOUBLE || net > LTR_NET_TRIPLE_FOLDED_32_64) return LTR_ERR_PARAM;
     if (net == LTR_NET_TWO_LAYER_64H || net == LTR_NET_TRIPLE_FOLDED) return 2 * n_cus;       /* 256-thread workgroups, two per CU (ltr_fcw.h) */
     return n_cus;
 }
@@ -1712,7 +1715,7 @@ int ltr_dropout_keep_mask(uint64_t seed, int layer, int64_t n_docs, int H, uint8
 int ltr_mlp_pack_sub(int net, int f, int h1, int h2, const float *W1, const float *b1, const float *W2, const float *b2,
                      const float *w3, const float *b3, float *packed, void *stream) {
     if (!W1 || !b1 || !w3 || !b3 || !packed) return LTR_ERR_NULL;
-    if ((!W2 || !b2) && net != LTR_NET_TWO_LAYER_64H && net != LTR_NET_TRIPLE_FOLDED && net != LTR_NET_TRIPLE_FOLDED_32) return LTR_ERR_NULL;     /* two-layer nets have no fc2 */
+    if ((!W2 || !b2) && net != LTR_NET_TWO_LAYER_64H && net != LTR_NET_TRIPLE_FOLDED && net != LTR_NET_TRIPLE_FOLDED_32 && net != LTR_NET_TRIPLE_FOLDED_32_64) return LTR_ERR_NULL;     /* two-layer nets have no fc2 */
     if (!aligned16(packed)) return LTR_ERR_ALIGN;
     LTR_FOR_NET(net, {
         if (f < 1 || f > NET::F || h1 < 1 || h1 > NET::H1 || h2 < 1 || h2 > NET::H2) return LTR_ERR_SHAPE;
@@ -1744,7 +1747,7 @@ int ltr_debug_set_stamps(void *buf, int tile) {
 static int fill_common(PipeArgs &a, int net, const float *X, int64_t n_docs, const float *packed, int dropout,
                        uint64_t seed, const uint8_t *keep1, const uint8_t *keep2) {
     if (!X || !packed) return LTR_ERR_NULL;
-    if (net < LTR_NET_DOUBLE || net > LTR_NET_TRIPLE_FOLDED_32) return LTR_ERR_PARAM;
+    if (net < LTR_NET_DOUBLE || net > LTR_NET_TRIPLE_FOLDED_32_64) return LTR_ERR_PARAM;
     if (n_docs < 0 || n_docs > ((int64_t)1 << 37)) return LTR_ERR_SHAPE;
     if (!aligned16(X) || !aligned16(packed)) return LTR_ERR_ALIGN;
     a = PipeArgs{};
@@ -1851,22 +1854,25 @@ int ltr_mlp_reduce_grads(int net, const float *partials, int grid, float *flat_g
     return ltr_mlp_reduce_grads_sub(net, info[0], info[1], info[2], partials, grid, flat_grad, stream);
 }
 
-int ltr_triple_fold(const float *W1, const float *b1, const float *W2, const float *b2, const float *w3, int copies, float *W1e,
+int ltr_triple_fold(const float *W1, const float *b1, const float *W2, const float *b2, const float *w3, int F, int copies, float *W1e,
                     float *b1e, float *w3e, void *stream) {
     if (!W1 || !b1 || !W2 || !b2 || !w3 || !W1e || !b1e || !w3e) return LTR_ERR_NULL;
+    if (F < 1 || F > 4096) return LTR_ERR_SHAPE;
     if (copies != 1 && copies != 2) return LTR_ERR_PARAM;
-    const int n = kTrH2 * (kTrF + 1);
-    hipLaunchKernelGGL(triple_fold_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, W1, b1, W2, b2, w3, copies, W1e, b1e,
+    const int n = kTrH2 * (F + 1);
+    hipLaunchKernelGGL(triple_fold_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, W1, b1, W2, b2, w3, F, copies, W1e, b1e,
                        w3e);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? LTR_OK : (int)e;
 }
 
-int ltr_triple_unfold_grads(const float *g2, int copies, const float *W1, const float *b1, const float *W2, float *flat, void *stream) {
+int ltr_triple_unfold_grads(const float *g2, int F, int copies, const float *W1, const float *b1, const float *W2, float *flat,
+                            void *stream) {
     if (!g2 || !W1 || !b1 || !W2 || !flat) return LTR_ERR_NULL;
+    if (F < 1 || F > 4096) return LTR_ERR_SHAPE;
     if (copies != 1 && copies != 2) return LTR_ERR_PARAM;
-    const int n = kTrH1 * kTrF + kTrH1 + kTrH2 * kTrH1 + kTrH2 + kTrH2 + 1;
-    hipLaunchKernelGGL(triple_unfold_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, g2, copies, W1, b1, W2, flat);
+    const int n = kTrH1 * F + kTrH1 + kTrH2 * kTrH1 + kTrH2 + kTrH2 + 1;
+    hipLaunchKernelGGL(triple_unfold_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, g2, F, copies, W1, b1, W2, flat);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? LTR_OK : (int)e;
 }

@@ -18,8 +18,8 @@ PROTOTYPES = {
     "ltr_mlp_backward_saved": (c_int, [c_int, P, c_int64, P, c_int, P, P, P, c_int, P]),
     "ltr_fused_step": (c_int, [c_int, c_int, P, P, c_int, c_int, P, c_int, c_uint64, P, P, c_float, c_float, c_float,
                                c_int, c_float, P, P, c_int, P]),
-    "ltr_triple_fold": (c_int, [P, P, P, P, P, c_int, P, P, P, P]),
-    "ltr_triple_unfold_grads": (c_int, [P, c_int, P, P, P, P, P]),
+    "ltr_triple_fold": (c_int, [P, P, P, P, P, c_int, c_int, P, P, P, P]),
+    "ltr_triple_unfold_grads": (c_int, [P, c_int, c_int, P, P, P, P, P]),
     "ltr_debug_set_stamps": (c_int, [P, c_int]),
     "ltr_fused_step_lambda": (c_int, [c_int, P, P, c_int, c_int, P, c_int, c_uint64, P, P, c_int, c_int, c_float, c_float,
                                       c_float, c_float, c_int, c_float, P, P, P, c_int, P]),

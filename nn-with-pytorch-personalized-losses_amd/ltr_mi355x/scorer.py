@@ -16,6 +16,7 @@ from ._lib import LtrError, check, lib
 from .functional import _ptr, _stream, require_device
 
 NET_DOUBLE, NET_TRIPLE, NET_DOUBLE_64, NET_TRIPLE_64, NET_TWO_LAYER_64H, NET_TRIPLE_FOLDED, NET_TRIPLE_FOLDED_32 = 0, 1, 2, 3, 4, 5, 6
+NET_TRIPLE_FOLDED_32_64 = 7
 NET_WIDE = -1       # more than 136 input features (neither of the reference's collections): see wide_forward
 COMPILED_FEATURES = {136: (NET_DOUBLE, NET_TRIPLE), 64: (NET_DOUBLE_64, NET_TRIPLE_64)}
 
@@ -117,22 +118,28 @@ def triple_folds(handle):
     ltr_triple_fold makes the folded weights from the six tensors every step, ltr_triple_unfold_grads turns the folded
     gradient into theirs.  LTR_TRIPLE_FOLD=0 keeps the layer-by-layer kernels (A/B, tests)."""
     import os
-    return handle == NET_TRIPLE and os.environ.get("LTR_TRIPLE_FOLD", "1") != "0"
+    return handle in (NET_TRIPLE, NET_TRIPLE_64) and os.environ.get("LTR_TRIPLE_FOLD", "1") != "0"
+
+
+def folded_net32(handle):
+    """The plain folded network (32 units, copies = 1) of a compiled TripleLayerNet: 136 features -> NET_TRIPLE_FOLDED_32 (the
+    one-launch step of that collection runs NET_TRIPLE_FOLDED on ltr_fcw.h instead), 64 features -> NET_TRIPLE_FOLDED_32_64 (every path)."""
+    return NET_TRIPLE_FOLDED_32 if handle == NET_TRIPLE else NET_TRIPLE_FOLDED_32_64
 
 
 def triple_fold(pf, copies, out=None):
-    """pf = [W1, b1, W2, b2, w3, b3] fp32 -> [W1e [32 copies, 136], b1e [32 copies], w3e [1, 32 copies]] (+ b3 unchanged)."""
+    """pf = [W1, b1, W2, b2, w3, b3] fp32 -> [W1e [32 copies, F], b1e [32 copies], w3e [1, 32 copies]] (+ b3 unchanged)."""
     dev = pf[0].device
-    R = 32 * copies
+    R, F = 32 * copies, int(pf[0].shape[1])
     if out is None:
-        out = [torch.empty(sh, dtype=torch.float32, device=dev) for sh in ((R, 136), (R,), (1, R))]
-    check(lib().ltr_triple_fold(*[_ptr(t) for t in pf[:5]], int(copies), *[_ptr(t) for t in out], _stream()), "ltr_triple_fold")
+        out = [torch.empty(sh, dtype=torch.float32, device=dev) for sh in ((R, F), (R,), (1, R))]
+    check(lib().ltr_triple_fold(*[_ptr(t) for t in pf[:5]], F, int(copies), *[_ptr(t) for t in out], _stream()), "ltr_triple_fold")
     return out
 
 
 def triple_unfold(g2, copies, pf, flat):
-    check(lib().ltr_triple_unfold_grads(_ptr(g2), int(copies), _ptr(pf[0]), _ptr(pf[1]), _ptr(pf[2]), _ptr(flat), _stream()),
-          "ltr_triple_unfold_grads")
+    check(lib().ltr_triple_unfold_grads(_ptr(g2), int(pf[0].shape[1]), int(copies), _ptr(pf[0]), _ptr(pf[1]), _ptr(pf[2]), _ptr(flat),
+                                        _stream()), "ltr_triple_unfold_grads")
 
 
 def reduce_grads(info, partials, grid, flat):
@@ -178,8 +185,8 @@ class _MLPScores(torch.autograd.Function):
                 # forward and backward launches of the folded 136 -> 32 -> 1 network (NET_TRIPLE_FOLDED_32); the six tensors'
                 # gradients come back through ltr_triple_unfold_grads
                 pf = _params_f32(params)
-                info = NetInfo.get(NET_TRIPLE_FOLDED_32)
-                packed = pack_params(NET_TRIPLE_FOLDED_32, triple_fold(pf, 1) + [pf[5]])
+                info = NetInfo.get(folded_net32(net))
+                packed = pack_params(info.handle, triple_fold(pf, 1) + [pf[5]])
                 ctx.fold_pf = pf[:3]
             else:
                 packed = pack_params(net, params)
@@ -205,7 +212,7 @@ class _MLPScores(torch.autograd.Function):
     def backward(ctx, g):
         x2, packed, k1, k2 = ctx.saved_tensors
         net, dropout, seed, grid, dtypes = ctx.meta
-        info = NetInfo.get(NET_TRIPLE_FOLDED_32 if ctx.fold_pf is not None else net)
+        info = NetInfo.get(folded_net32(net) if ctx.fold_pf is not None else net)
         dev = x2.device
         n = x2.shape[0]
         with torch.cuda.device(dev):
@@ -359,10 +366,11 @@ class FusedRanker:
         # 136 -> 32 -> 1 network (NET_TRIPLE_FOLDED_32)
         self.fold = self.fold32 = None
         if triple_folds(self.info.handle):
-            fi, fi32 = NetInfo.get(NET_TRIPLE_FOLDED), NetInfo.get(NET_TRIPLE_FOLDED_32)
+            fi32 = NetInfo.get(folded_net32(self.info.handle))
+            fi = NetInfo.get(NET_TRIPLE_FOLDED) if self.info.handle == NET_TRIPLE else fi32      # 64 features: the plain form everywhere
             self.fold, self.fold32 = fi, fi32
             self.fold_grid = int(grid) if grid else int(lib().ltr_fused_grid(fi.net, cu_count(dev)))
-            self.fold_w = [torch.empty(sh, dtype=torch.float32, device=dev) for sh in ((64, 136), (64,), (1, 64))]
+            self.fold_w = [torch.empty(sh, dtype=torch.float32, device=dev) for sh in ((64, self.info.F), (64,), (1, 64))]
             self.fold_packed = torch.empty(max(fi.packed_floats, fi32.packed_floats), dtype=torch.float32, device=dev)
             self.fold_partials = torch.empty(max(self.fold_grid * fi.partial_floats, self.grid * fi32.partial_floats), dtype=torch.float32,
                                              device=dev)

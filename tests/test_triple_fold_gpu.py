@@ -27,20 +27,20 @@ def dev():
     return torch.device("cuda:0")
 
 
-def _weights(dev, seed):
+def _weights(dev, seed, F=136):
     g = torch.Generator().manual_seed(seed)
-    W1, b1 = torch.randn(64, 136, generator=g) * 0.2, torch.randn(64, generator=g) * 0.1
+    W1, b1 = torch.randn(64, F, generator=g) * 0.2, torch.randn(64, generator=g) * 0.1
     W2, b2 = torch.randn(32, 64, generator=g) * 0.3, torch.randn(32, generator=g) * 0.1
     w3 = torch.randn(1, 32, generator=g)
     return [t.to(dev).contiguous() for t in (W1, b1, W2, b2, w3)]
 
 
-@pytest.mark.parametrize("copies", [1, 2])
-def test_fold_kernel(dev, copies):
+@pytest.mark.parametrize("copies,F", [(1, 136), (2, 136), (1, 64)])
+def test_fold_kernel(dev, copies, F):
     from ltr_mi355x.scorer import triple_fold
-    W1, b1, W2, b2, w3 = _weights(dev, 1)
+    W1, b1, W2, b2, w3 = _weights(dev, 1, F)
     W1e, b1e, w3e = triple_fold([W1, b1, W2, b2, w3], copies)
-    assert tuple(W1e.shape) == (32 * copies, 136) and tuple(b1e.shape) == (32 * copies,) and tuple(w3e.shape) == (1, 32 * copies)
+    assert tuple(W1e.shape) == (32 * copies, F) and tuple(b1e.shape) == (32 * copies,) and tuple(w3e.shape) == (1, 32 * copies)
     ref_W = (W2.double() @ W1.double())
     ref_b = W2.double() @ b1.double() + b2.double()
     for c in range(copies):
@@ -51,29 +51,29 @@ def test_fold_kernel(dev, copies):
         assert torch.equal(W1e[:32], W1e[32:]) and torch.equal(b1e[:32], b1e[32:])
     from ltr_mi355x import lib
     from ltr_mi355x.functional import _ptr, _stream
-    assert lib().ltr_triple_fold(_ptr(W1), _ptr(b1), _ptr(W2), _ptr(b2), _ptr(w3), 3, _ptr(W1e), _ptr(b1e), _ptr(w3e), _stream()) != 0
+    assert lib().ltr_triple_fold(_ptr(W1), _ptr(b1), _ptr(W2), _ptr(b2), _ptr(w3), F, 3, _ptr(W1e), _ptr(b1e), _ptr(w3e), _stream()) != 0
 
 
-@pytest.mark.parametrize("copies", [1, 2])
-def test_unfold_kernel(dev, copies):
+@pytest.mark.parametrize("copies,F", [(1, 136), (2, 136), (1, 64)])
+def test_unfold_kernel(dev, copies, F):
     from ltr_mi355x.scorer import triple_unfold
-    W1, b1, W2, b2, w3 = _weights(dev, 2)
+    W1, b1, W2, b2, w3 = _weights(dev, 2, F)
     g = torch.Generator().manual_seed(3)
     R = 32 * copies
-    g2 = torch.randn(R * 136 + R + R + 1, generator=g).to(dev)
-    flat = torch.empty(64 * 136 + 64 + 32 * 64 + 32 + 32 + 1, device=dev)
+    g2 = torch.randn(R * F + R + R + 1, generator=g).to(dev)
+    flat = torch.empty(64 * F + 64 + 32 * 64 + 32 + 32 + 1, device=dev)
     triple_unfold(g2, copies, [W1, b1, W2], flat)
     d = g2.double()
-    GW = d[:R * 136].view(copies, 32, 136)
+    GW = d[:R * F].view(copies, 32, F)
     G = GW.sum(0)
-    gb = d[R * 136:R * 136 + R].view(copies, 32).sum(0)
-    gw3 = d[R * 136 + R:R * 136 + 2 * R].view(copies, 32).sum(0)
+    gb = d[R * F:R * F + R].view(copies, 32).sum(0)
+    gw3 = d[R * F + R:R * F + 2 * R].view(copies, 32).sum(0)
     ref = torch.cat([(W2.double().t() @ G).reshape(-1), W2.double().t() @ gb, (G @ W1.double().t() + gb[:, None] * b1.double()[None, :]).reshape(-1),
                      gb, gw3, d[-1:]])
     assert relerr(flat.cpu().numpy(), ref.cpu().numpy()) < 1e-7
     # piecewise too: a small tensor must not hide behind the largest one
     off = 0
-    for n in (64 * 136, 64, 32 * 64, 32, 32, 1):
+    for n in (64 * F, 64, 32 * 64, 32, 32, 1):
         assert relerr(flat[off:off + n].cpu().numpy(), ref[off:off + n].cpu().numpy()) < 1e-6
         off += n
 
@@ -177,4 +177,34 @@ def test_three_launch_path_folded(loss, S, dev):
     rl, rg, _ = _oracle_step("triple", sd, x, y, loss)
     _, rg32, _ = _oracle_step("triple", sd, x, y, loss, dtype=torch.float32)
     assert abs(l - float(rl)) <= 1e-5 * max(1.0, abs(float(rl)))
+    assert_grads(_grads(net), rg, ref32=rg32)
+
+
+@pytest.mark.parametrize("loss,S,B", [("approxNDCG", 128, 9), ("listnet", 64, 20), ("lambdaLoss", 32, 33), ("approxNDCG", 50, 6)])
+def test_64_feature_network_folded(loss, S, B, dev, monkeypatch):
+    """TripleLayerNet(64) (TD2003): one-launch and three-launch steps and the module path run the folded 64 -> 32 -> 1 network on
+    the generic pipeline; against the layer-by-layer kernels and the fp64 oracle."""
+    from ltr_mi355x.scorer import FusedRanker
+    net, sd = _make("triple", dev, 41, F=64)
+    gen = torch.Generator().manual_seed(7 * S + B)
+    x = torch.randn(B, S, 64, generator=gen)
+    y = torch.randint(0, 5, (B, S), generator=gen).float()
+    y[0, S - 3:] = -1.0
+    xd, yd = x.to(dev), y.to(dev)
+    kw = dict(weighing_scheme="ndcgLoss2PP_scheme") if loss == "lambdaLoss" else {}
+    folded = FusedRanker(net, loss=loss, **kw)
+    assert folded.fold is not None and folded.fold.F == 64 and folded.fold.H1 == 32
+    lf = float(folded.step(xd, yd))
+    gf = {k: v.copy() for k, v in _grads(net).items()}
+    rl, rg, rs = _oracle_step("triple", sd, x, y, loss)
+    _, rg32, _ = _oracle_step("triple", sd, x, y, loss, dtype=torch.float32)
+    assert abs(lf - float(rl)) <= 1e-5 * max(1.0, abs(float(rl)))
+    assert_grads(gf, rg, ref32=rg32)
+    sm = net(xd, None, None).squeeze(-1).detach().cpu().numpy()                 # module path, folded
+    assert relerr(sm, rs) < 1e-5
+    monkeypatch.setenv("LTR_TRIPLE_FOLD", "0")
+    plain = FusedRanker(net, loss=loss, **kw)
+    assert plain.fold is None
+    lp = float(plain.step(xd, yd))
+    assert abs(lp - float(rl)) <= 1e-5 * max(1.0, abs(float(rl)))
     assert_grads(_grads(net), rg, ref32=rg32)
