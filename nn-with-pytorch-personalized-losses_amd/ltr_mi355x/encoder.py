@@ -134,6 +134,15 @@ def stream_fc(i): return 100000 + i
 _NBLK = 512     # workgroups (= partial rows) of the column-sum style reductions
 
 
+def _small_step_splits(M, N, K):
+    """Split-K factor for an activation-shaped GEMM (M tokens x N) whose 128 x 128 output tiles do not fill the chip while its k loop is
+    long (the GEMM-path FFN's dn2 = dz1 W1 at a few thousand tokens: 32 tiles x 32 k-steps): up to 4 slices, each at least 8 k-steps."""
+    tiles = ((M + 127) // 128) * ((N + 127) // 128)
+    if tiles >= 128 or K < 1024:
+        return 1
+    return max(1, min(4, 256 // tiles, K // 512))
+
+
 def _dw_splits(M, N, K):
     """Split-K factor of a weight-gradient GEMM: enough (tile, slice) workgroups to fill the chip (~512), at least 256
     tokens (4 k-steps) per slice."""
@@ -462,7 +471,13 @@ def _body_backward(spec, seed, st, dx, want_dx=False):
                 gb1 = _colsum(dz1, T, dff)
                 gW1 = _weight_grad(dz1, n2, T, dff, d)
                 dn2 = torch.empty((T, d), dtype=torch.float32, device=dev)
-                gemm(dz1, w116, T, d, dff, b_kmajor=True, Cf=dn2)
+                ks = _small_step_splits(T, d, dff)
+                if ks > 1:          # few output tiles and a long k loop: split-K partials + one reduce (32 workgroups -> 32 ks)
+                    parts = torch.empty((ks, T, d), dtype=torch.float32, device=dev)
+                    gemm(dz1, w116, T, d, dff, b_kmajor=True, Cf=parts, splits=ks)
+                    sum_partials(parts, ks, T * d, out=dn2.view(-1))
+                else:
+                    gemm(dz1, w116, T, d, dff, b_kmajor=True, Cf=dn2)
             ga2, gb2n = layernorm_bwd(x1, a2, dn2, T, d, LN_EPS, 0, dx)
             # attention sublayer: x1 = x0 + drop(ctx Wo^T + bo)
             dyo, gbo = _drop_cast_colsum(dx, T, d, p_enc, seed, stream_attn_out(l))

@@ -638,7 +638,8 @@ def test_small_steps_take_the_gemm_ffn_path_by_default(enc, monkeypatch):
     assert E.fused_ffn_enabled(128, 2048, 16)
     monkeypatch.setattr(LTRModel, "_ltr_next_seed", lambda self: 77)
     torch.manual_seed(5)
-    net = make_model(dict(sizes=[128], input_norm=False, activation=None, dropout=0.0), dict(N=2, d_ff=512, h=8, dropout=0.1,
+    assert E._small_step_splits(384, 128, 1024) == 2 and E._small_step_splits(4096, 128, 2048) == 4 and E._small_step_splits(65536, 128, 2048) == 1
+    net = make_model(dict(sizes=[128], input_norm=False, activation=None, dropout=0.0), dict(N=2, d_ff=1024, h=8, dropout=0.1,
                      positional_encoding=None), dict(d_output=1, output_activation=None), 136).to(DEV).train()
     x = torch.randn(6, 64, 136, device=DEV)
     y = torch.randint(0, 5, (6, 64), device=DEV).float()
