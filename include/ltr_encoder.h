@@ -42,6 +42,11 @@ int ltr_enc_attn_dropout_mask(uint64_t seed, int stream_id, int B, int S, int h,
 
 /* out[i] = sum_z parts[z*n + i], z in [0, nsplit) in that fixed order (fp64 accumulator); accumulate != 0: out += . */
 int ltr_enc_sum_partials(const float *parts, int nsplit, int64_t n, int accumulate, float *out, void *stream);
+/* Epilogue of a split-K activation GEMM (ltr_enc_gemm_bf16 with splits > 1 writes raw partials [splits][M][N]):
+ * out [M][N] = residual + dropout(sum_s parts[s] + bias), the arithmetic and dropout stream of the GEMM's own epilogue
+ * (transformer.py:231-237 followed by the SublayerConnection residual, :107-114).  bias / residual may be NULL; N % 4 == 0. */
+int ltr_enc_splitk_epilogue(const float *parts, int nsplit, int64_t M, int N, const float *bias, float drop_p, uint64_t seed, int stream_id,
+                            const float *residual, float *out, void *stream);
 
 /* The same for `njobs` independent reductions in as few launches as possible (16 jobs per launch); `jobs` is a HOST array. */
 typedef struct ltr_reduce_job {

@@ -213,6 +213,31 @@ __global__ void __launch_bounds__(256) sum_partials_kernel(const float *__restri
     __shared__ double red[256];
     sum_partials_any(parts, nsplit, n, n, accumulate, out, blockIdx.x, gridDim.x, red);
 }
+// The epilogue of a split-K activation GEMM whose result goes through bias + dropout + residual (the GEMM-path FFN's second layer at
+// small steps): out[m][n] = residual[m][n] + drop(sum_s parts[s][m][n] + bias[n]), the same arithmetic, dropout stream and
+// element order as gemm_bf16_kernel's own epilogue.  N a multiple of 4; four elements (one hash word) per thread.
+__global__ void __launch_bounds__(256) splitk_epilogue_kernel(const float *__restrict__ parts, int nsplit, long long M, int N,
+                                                              const float *__restrict__ bias, float drop_p, unsigned long long seed,
+                                                              int stream_id, const float *__restrict__ residual, float *__restrict__ out) {
+    const long long quads = M * (N / 4);
+    const unsigned thr = drop_threshold(drop_p);
+    const float keep_scale = thr ? 1.f / (1.f - drop_p) : 1.f;
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < quads; e += (long long)gridDim.x * blockDim.x) {
+        const long long m = e / (N / 4);
+        const int n = 4 * (int)(e % (N / 4));
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        for (int sp = 0; sp < nsplit; ++sp) v += *reinterpret_cast<const f32x4 *>(parts + ((long long)sp * M + m) * N + n);
+        if (bias) v += *reinterpret_cast<const f32x4 *>(bias + n);
+        if (thr) {
+            const Keep4 keep = drop_keep4b(seed, stream_id, (unsigned long long)m * N + n, thr);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = keep.k[r] ? v[r] * keep_scale : 0.f;
+        }
+        if (residual) v += *reinterpret_cast<const f32x4 *>(residual + m * N + n);
+        *reinterpret_cast<f32x4 *>(out + m * N + n) = v;
+    }
+}
+
 // up to kReduceJobs independent reductions in one launch (blockIdx.y = job): the backward of one training step ends in
 // ~60 of them, each a few microseconds of work
 constexpr int kReduceJobs = 16;
@@ -2087,6 +2112,17 @@ int ltr_enc_sum_partials(const float *parts, int nsplit, int64_t n, int accumula
     const int ew = 256 / reduce_zl(nsplit, n);
     hipLaunchKernelGGL(sum_partials_kernel, dim3(elt_grid(n, ew)), dim3(256), 0, (hipStream_t)stream, parts, nsplit, (long long)n,
                        accumulate, out);
+    return status();
+}
+
+int ltr_enc_splitk_epilogue(const float *parts, int nsplit, int64_t M, int N, const float *bias, float drop_p, uint64_t seed, int stream_id,
+                            const float *residual, float *out, void *stream) {
+    if (!parts || !out) return LTR_ERR_NULL;
+    if (nsplit < 1 || M < 0 || N < 4 || N % 4) return LTR_ERR_SHAPE;
+    if (!(drop_p >= 0.f) || !(drop_p < 1.f)) return LTR_ERR_PARAM;
+    if (M == 0) return LTR_OK;
+    hipLaunchKernelGGL(splitk_epilogue_kernel, dim3(elt_grid(M * (N / 4), 256)), dim3(256), 0, (hipStream_t)stream, parts, nsplit,
+                       (long long)M, N, bias, drop_p, (unsigned long long)seed, stream_id, residual, out);
     return status();
 }
 

@@ -49,6 +49,7 @@ _PROTOTYPES = {
     "ltr_gather_rows_f32": (c_int, [P, c_int64, P, c_int64, c_int64, P, P]),
     # include/ltr_encoder.h (row f-3)
     "ltr_enc_cast_bf16": (c_int, [P, P, c_int64, P]),
+    "ltr_enc_splitk_epilogue": (c_int, [P, c_int, c_int64, c_int, P, c_float, c_uint64, c_int, P, P, P]),
     "ltr_enc_seed_set": (c_int, [c_uint64, P]),
     "ltr_enc_seed_advance": (c_int, [c_uint64, P]),
     "ltr_enc_seed_get": (c_int, [ctypes.POINTER(c_uint64)]),

@@ -374,7 +374,14 @@ def _run_forward(spec, x, mask, seed, training, params):
                 hid = torch.empty((T, dff), dtype=_U16, device=dev)
                 gemm(n2, w116, T, dff, d, Cb=hid, bias=b1, relu=True, drop_p=p_enc, seed=seed, drop_stream=stream_ffn_hidden(l))
                 x2 = torch.empty((T, d), dtype=torch.float32, device=dev)
-                gemm(hid, w216, T, d, dff, Cf=x2, bias=b2, residual=x1, drop_p=p_enc, seed=seed, drop_stream=stream_ffn_out(l))
+                ks = _small_step_splits(T, d, dff)
+                if ks > 1:          # 32 output tiles, 32 k-steps each: split-K partials, then bias + dropout + residual in the reduce
+                    parts = torch.empty((ks, T, d), dtype=torch.float32, device=dev)
+                    gemm(hid, w216, T, d, dff, Cf=parts, splits=ks)
+                    check(lib().ltr_enc_splitk_epilogue(_ptr(parts), ks, T, d, _ptr(b2), float(p_enc), int(seed) & (2 ** 64 - 1),
+                                                        stream_ffn_out(l), _ptr(x1), _ptr(x2), _stream()), "ltr_enc_splitk_epilogue")
+                else:
+                    gemm(hid, w216, T, d, dff, Cf=x2, bias=b2, residual=x1, drop_p=p_enc, seed=seed, drop_stream=stream_ffn_out(l))
             st["layers"].append((x0, n1, qkv, ctxb, x1, n2, hid, lse))
             stream_x = x2
     st["xin"], st["prm"], st["final_x"] = xin, prm, stream_x
