@@ -367,9 +367,7 @@ __global__ void __launch_bounds__(kFcwThreads, 2) fcw_fused_kernel(const PipeArg
         // score partial w3 . h1 over my 16 hidden units: sum over the 16 lanes of a DPP row, for each of my 32 documents
 #pragma unroll
         for (int T = 0; T < NTW; ++T) {
-            f32x4 sv;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) sv[r] = row_sum_to_lane15(h1[T][r] * w3n);
+            const f32x4 sv = row_sum4_to_lane15(h1[T] * w3n);
             if (d == 15) *reinterpret_cast<f32x4 *>(part + w * kTileDocs + 16 * (T0 + T) + 4 * q) = sv;
         }
         FCW_STAMP(5)

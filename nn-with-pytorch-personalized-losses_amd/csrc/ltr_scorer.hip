@@ -210,13 +210,35 @@ __device__ __forceinline__ unsigned keep_word(unsigned long long seed, int layer
 
 // Sum over the 16 lanes of a DPP row (= the 16 documents sharing one q); the total lands in lane 15 of the row.
 __device__ __forceinline__ float row_sum_to_lane15(float v) {
-#define LTR_DPP_SHR(x, n) __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x110 + (n), 0xF, 0xF, false))
+#define LTR_DPP_SHR(x, n) __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x110 + (n), 0xF, 0xF, true))
     v += LTR_DPP_SHR(v, 1);
     v += LTR_DPP_SHR(v, 2);
     v += LTR_DPP_SHR(v, 4);
     v += LTR_DPP_SHR(v, 8);
 #undef LTR_DPP_SHR
     return v;
+}
+// The same for FOUR values at once, every step as ONE v_add_f32_dpp: hipcc fuses only the row_shr:2 / :4 steps of the form above and
+// expands the other two into copy + v_mov_b32_dpp + v_add_f32 (two extra instructions per step and value, in kernels whose non-matrix
+// time is instruction count).  The four chains are interleaved, so a DPP read is always >= 3 instructions behind the write of its
+// source (the hardware wants 2 wait states); the leading s_nop covers the caller's last write.
+#ifndef LTR_ROWSUM_ASM
+#define LTR_ROWSUM_ASM 1
+#endif
+__device__ __forceinline__ f32x4 row_sum4_to_lane15(f32x4 v) {
+#if LTR_ROWSUM_ASM
+    float a = v[0], b = v[1], c = v[2], d = v[3];
+#define LTR_ROWSUM_STEP(n)                                                                  \
+    "v_add_f32_dpp %0, %0, %0 row_shr:" #n " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"   \
+    "v_add_f32_dpp %1, %1, %1 row_shr:" #n " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"   \
+    "v_add_f32_dpp %2, %2, %2 row_shr:" #n " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"   \
+    "v_add_f32_dpp %3, %3, %3 row_shr:" #n " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+    asm("s_nop 1\n\t" LTR_ROWSUM_STEP(1) LTR_ROWSUM_STEP(2) LTR_ROWSUM_STEP(4) LTR_ROWSUM_STEP(8) : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
+#undef LTR_ROWSUM_STEP
+    return f32x4{a, b, c, d};
+#else
+    return f32x4{row_sum_to_lane15(v[0]), row_sum_to_lane15(v[1]), row_sum_to_lane15(v[2]), row_sum_to_lane15(v[3])};
+#endif
 }
 
 // z^T tiles = W fragments x B fragments for the wave's 16-document tile.
@@ -1152,13 +1174,13 @@ __global__ void __launch_bounds__(kThreads, 2) slate_pipeline_kernel(const PipeA
 #pragma unroll
         for (int To = 0; To < N::NT2; ++To) {
             const f32x4 wv = *reinterpret_cast<const f32x4 *>(w3s + 16 * To + 4 * q);
+            const f32x4 sv = row_sum4_to_lane15(h2[To] * ds0);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const float v = row_sum_to_lane15(ds0 * h2[To][r]);
                 // fire-and-forget ds_add_f32 into this wave's private slot: single adder per address, program
                 // order across tiles -> deterministic, and no read-modify-write round trip on the critical path
                 if (d == 15)
-                    __hip_atomic_fetch_add(&dw3[w * N::NT2 * 16 + 16 * To + 4 * q + r], v, __ATOMIC_RELAXED,
+                    __hip_atomic_fetch_add(&dw3[w * N::NT2 * 16 + 16 * To + 4 * q + r], sv[r], __ATOMIC_RELAXED,
                                            __HIP_MEMORY_SCOPE_WORKGROUP);
                 h2[To][r] = apply_act_grad<N::A2>(ds2 * wv[r], h2[To][r]);
             }
